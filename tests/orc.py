@@ -1,0 +1,183 @@
+"""ctypes wrapper around oracle/librt_oracle.so -- TEST INFRASTRUCTURE ONLY.
+
+The oracle is the checker: only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import this module.  Nothing under raytracer_amd/ does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_SO = os.path.join(_ROOT, "oracle", "librt_oracle.so")
+
+_f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+_i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+_u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+_u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+
+
+def _load():
+    if not os.path.exists(_SO):
+        subprocess.check_call(["make", "-C", os.path.join(_ROOT, "oracle"), "librt_oracle.so"])
+    lib = C.CDLL(_SO)
+    lib.orc_rng_new.restype = C.c_void_p
+    lib.orc_rng_new.argtypes = [C.c_uint32]
+    lib.orc_rng_free.argtypes = [C.c_void_p]
+    lib.orc_rng_seed.argtypes = [C.c_void_p, C.c_uint32]
+    lib.orc_rng_u32.restype = C.c_uint32
+    lib.orc_rng_u32.argtypes = [C.c_void_p]
+    lib.orc_rng_double.restype = C.c_double
+    lib.orc_rng_double.argtypes = [C.c_void_p]
+    lib.orc_rng_discard.argtypes = [C.c_void_p, C.c_uint64]
+    lib.orc_rng_fill_u32.argtypes = [C.c_void_p, _u32p, C.c_uint64]
+    lib.orc_rng_fill_double.argtypes = [C.c_void_p, _f64p, C.c_uint64]
+    lib.orc_rng_get_state.argtypes = [C.c_void_p, _u32p, C.POINTER(C.c_int)]
+    lib.orc_build.restype = C.c_void_p
+    lib.orc_build.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _i64p, C.c_int]
+    lib.orc_scene_free.argtypes = [C.c_void_p]
+    lib.orc_scene_counts.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_long)]
+    lib.orc_tlas_nodes.argtypes = [C.c_void_p, _f64p, _i32p, _i32p, _i32p]
+    lib.orc_slot_info.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.orc_slot_nodes.argtypes = [C.c_void_p, C.c_int, _f64p, _i32p, _i64p, _i32p]
+    lib.orc_slot_indices.argtypes = [C.c_void_p, C.c_int, _i32p]
+    lib.orc_trace.argtypes = [C.c_void_p, C.c_int64, _f64p, _f64p] + [C.c_void_p] * 7 + [
+        C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.orc_render_rows.argtypes = [C.c_void_p, _f64p, _f64p, _f64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                    C.POINTER(C.c_uint64)]
+    lib.orc_normalized.argtypes = [_f64p, _f64p]
+    lib.orc_pixel_sample.argtypes = [_f64p, _f64p, C.c_int, C.c_int, C.c_double, C.c_double, _f64p]
+    lib.orc_slab.restype = C.c_int
+    lib.orc_slab.argtypes = [_f64p, _f64p, _f64p, _f64p]
+    lib.orc_moller_trumbore.restype = C.c_double
+    lib.orc_moller_trumbore.argtypes = [_f64p, _f64p, _f64p, _f64p]
+    lib.orc_shade_hit.argtypes = [_f64p, _f64p, _f64p]
+    lib.orc_shade_sky.argtypes = [C.c_double, _f64p]
+    lib.orc_quantise.restype = C.c_int
+    lib.orc_quantise.argtypes = [_f64p, C.c_int, C.POINTER(C.c_double)]
+    return lib
+
+
+lib = _load()
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Rng:
+    """std::mt19937 + uniform_real_distribution<double>(0,1) as used by rtmathutils.h:15-19."""
+
+    def __init__(self, seed=5489):
+        self.h = lib.orc_rng_new(seed)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib.orc_rng_free(self.h)
+            self.h = None
+
+    def u32(self, n):
+        out = np.empty(n, np.uint32)
+        lib.orc_rng_fill_u32(self.h, out, n)
+        return out
+
+    def doubles(self, n):
+        out = np.empty(n, np.float64)
+        lib.orc_rng_fill_double(self.h, out, n)
+        return out
+
+    def discard(self, n):
+        lib.orc_rng_discard(self.h, int(n))
+
+    def state(self):
+        mt = np.empty(624, np.uint32)
+        idx = C.c_int()
+        lib.orc_rng_get_state(self.h, mt, C.byref(idx))
+        return mt, idx.value
+
+
+class Scene:
+    """Reference-shaped tree built by the oracle for one timestep.
+
+    coords: list of (T,E,3,3) f64 arrays; colors: list of (T,E,3) f64 arrays."""
+
+    def __init__(self, coords, colors, timestep=0):
+        self.coords = [np.ascontiguousarray(c, np.float64) for c in coords]
+        self.colors = [np.ascontiguousarray(c, np.float64) for c in colors]
+        n = len(self.coords)
+        cp = (C.c_void_p * n)(*[c.ctypes.data for c in self.coords])
+        kp = (C.c_void_p * n)(*[c.ctypes.data for c in self.colors])
+        counts = np.array([c.shape[1] for c in self.colors], np.int64)
+        self.h = lib.orc_build(n, cp, kp, counts, int(timestep))
+        a, b, m = C.c_int(), C.c_int(), C.c_long()
+        lib.orc_scene_counts(self.h, C.byref(a), C.byref(b), C.byref(m))
+        self.n_tlas_nodes, self.n_slots, self.midpoint_msgs = a.value, b.value, m.value
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib.orc_scene_free(self.h)
+            self.h = None
+
+    def tlas(self):
+        n = self.n_tlas_nodes
+        boxes = np.empty((n, 6))
+        cnt, left, mn = (np.empty(n, np.int32) for _ in range(3))
+        lib.orc_tlas_nodes(self.h, boxes, cnt, left, mn)
+        return dict(boxes=boxes, blas_count=cnt, left=left, min_blas_idx=mn)
+
+    def slot(self, s):
+        mesh, nn, ne = C.c_int(), C.c_int(), C.c_int()
+        lib.orc_slot_info(self.h, s, C.byref(mesh), C.byref(nn), C.byref(ne))
+        boxes = np.empty((nn.value, 6))
+        left = np.empty(nn.value, np.int32)
+        count = np.empty(nn.value, np.int64)
+        min_idx = np.empty(nn.value, np.int32)
+        lib.orc_slot_nodes(self.h, s, boxes, left, count, min_idx)
+        idx = np.empty(max(ne.value, 1), np.int32)[: ne.value]
+        idx = np.ascontiguousarray(idx)
+        if ne.value:
+            lib.orc_slot_indices(self.h, s, idx)
+        return dict(mesh=mesh.value, boxes=boxes, left=left, count=count, min_idx=min_idx, indices=idx)
+
+    def trace(self, origins, dirs):
+        o = np.ascontiguousarray(origins, np.float64).reshape(-1, 3)
+        d = np.ascontiguousarray(dirs, np.float64).reshape(-1, 3)
+        n = o.shape[0]
+        t = np.empty(n)
+        bary = np.empty((n, 3))
+        col = np.empty((n, 3))
+        slot, mesh, elem, pos = (np.empty(n, np.int32) for _ in range(4))
+        nn, nt = C.c_uint64(), C.c_uint64()
+        lib.orc_trace(self.h, n, o, d, _ptr(t), _ptr(bary), _ptr(col), _ptr(slot), _ptr(mesh), _ptr(elem),
+                      _ptr(pos), C.byref(nn), C.byref(nt))
+        return dict(t=t, bary=bary, color=col, slot=slot, mesh=mesh, elem=elem, sorted_pos=pos,
+                    nodes=nn.value, tris=nt.value)
+
+    def render(self, cam, p00, spacing, H, W, spp, rng=None, jitter=None, row0=0, row1=None, want_hits=True):
+        row1 = H if row1 is None else row1
+        cam = np.ascontiguousarray(cam, np.float64).reshape(3)
+        p00 = np.ascontiguousarray(p00, np.float64).reshape(3)
+        sp = np.ascontiguousarray(spacing, np.float64).reshape(6)
+        npix = (row1 - row0) * W
+        rgb = np.empty((row1 - row0, W, 3), np.uint8)
+        inten = np.empty((row1 - row0, W))
+        hm = he = ht = None
+        if want_hits:
+            hm = np.empty(npix * spp, np.int32)
+            he = np.empty(npix * spp, np.int32)
+            ht = np.empty(npix * spp)
+        if jitter is not None:
+            jitter = np.ascontiguousarray(jitter, np.float64).reshape(-1)
+            assert jitter.size == npix * spp * 2
+        elif rng is None:
+            rng = Rng()
+        nn, nt, nh = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        lib.orc_render_rows(self.h, cam, p00, sp, H, W, spp, row0, row1, rng.h if rng is not None else None,
+                            _ptr(jitter), _ptr(rgb), _ptr(inten), _ptr(hm), _ptr(he), _ptr(ht),
+                            C.byref(nn), C.byref(nt), C.byref(nh))
+        return dict(rgb=rgb, intensity=inten, hit_mesh=hm, hit_elem=he, hit_t=ht, nodes=nn.value, tris=nt.value,
+                    hits=nh.value)

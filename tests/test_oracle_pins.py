@@ -1,0 +1,133 @@
+"""Pin the CPU oracle (oracle/rt_oracle.c) before trusting it.
+
+The reference's hot-path .cpp files are unbuildable here (nanobind absent), so the pins are:
+  * the reference's own random_double() (cpp/rtmathutils.h:15-19), compiled from the mount by
+    oracle/eigen_probe.cpp -> tests/golden/eigen_probe.npz (rng_*)
+  * Eigen evaluation order of every expression shape on the path, evaluated with the reference's
+    vendored Eigen headers by the same probe (norm_*, ps_*, mt_*, slab_*, shade_*, quant_*)
+  * MT19937's published known answer (10000th output of seed 5489 is 4123659995, C++11 [rand.predef])
+All comparisons are on bit patterns.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import orc
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    return np.load(os.path.join(golden_dir, "eigen_probe.npz"))
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float64).view(np.uint64)
+
+
+def test_mt19937_known_answer():
+    r = orc.Rng(5489)
+    w = r.u32(10000)
+    assert int(w[0]) == 3499211612
+    assert int(w[-1]) == 4123659995
+
+
+def test_rng_matches_reference_random_double(gold):
+    r = orc.Rng(5489)
+    d = r.doubles(gold["rng_doubles"].size)
+    assert np.array_equal(bits(d), bits(gold["rng_doubles"]))
+    assert np.array_equal(r.u32(gold["rng_words_after"].size), gold["rng_words_after"])
+    assert d.min() >= 0.0 and d.max() < 1.0
+
+
+def test_rng_discard_and_state():
+    a, b = orc.Rng(), orc.Rng()
+    a.discard(12345)
+    b.u32(12345)
+    assert np.array_equal(a.u32(700), b.u32(700))
+
+
+def test_normalized(gold):
+    vin = gold["norm_in"].reshape(-1, 3)
+    out = np.empty_like(vin)
+    for i in range(vin.shape[0]):
+        o = np.empty(3)
+        orc.lib.orc_normalized(np.ascontiguousarray(vin[i]), o)
+        out[i] = o
+    assert np.array_equal(bits(out), bits(gold["norm_out"].reshape(-1, 3)))
+
+
+def test_pixel_sample_and_direction(gold):
+    cam = gold["ps_cam"].reshape(-1, 3)
+    p00 = gold["ps_p00"].reshape(-1, 3)
+    sp = gold["ps_spacing"].reshape(-1, 6)
+    off = gold["ps_off"].reshape(-1, 2)
+    ij = gold["ps_ij"].reshape(-1, 2)
+    want_ps = gold["ps_sample"].reshape(-1, 3)
+    want_dir = gold["ps_dir"].reshape(-1, 3)
+    for q in range(cam.shape[0]):
+        ps = np.empty(3)
+        orc.lib.orc_pixel_sample(np.ascontiguousarray(p00[q]), np.ascontiguousarray(sp[q]), int(ij[q, 0]),
+                                 int(ij[q, 1]), float(off[q, 0]), float(off[q, 1]), ps)
+        assert np.array_equal(bits(ps), bits(want_ps[q])), q
+        d = np.empty(3)
+        orc.lib.orc_normalized(ps - cam[q], d)
+        assert np.array_equal(bits(d), bits(want_dir[q])), q
+
+
+def test_moller_trumbore_and_first_min(gold):
+    cnt = gold["mt_count"]
+    o = gold["mt_origin"].reshape(-1, 3)
+    d = gold["mt_dir"].reshape(-1, 3)
+    tris = gold["mt_tris"].reshape(-1, 9)
+    k = 0
+    n_hits = n_ties = 0
+    for b in range(cnt.size):
+        ts = []
+        for r in range(cnt[b]):
+            bary = np.empty(3)
+            t = orc.lib.orc_moller_trumbore(np.ascontiguousarray(o[b]), np.ascontiguousarray(d[b]),
+                                            np.ascontiguousarray(tris[k]), bary)
+            assert bits([t])[0] == bits([gold["mt_t"][k]])[0], (b, r)
+            assert np.array_equal(bits(bary), bits([gold["mt_u"][k], gold["mt_v"][k], gold["mt_w"][k]])), (b, r)
+            ts.append(t)
+            k += 1
+        ts = np.array(ts)
+        first_min = int(np.argmin(ts))  # numpy argmin == first minimal index, as Eigen's strict-< scan
+        assert first_min == int(gold["mt_argmin"][b])
+        n_hits += int(np.isfinite(ts).any())
+        n_ties += int(np.isfinite(ts.min()) and (ts == ts.min()).sum() > 1)
+    assert k == tris.shape[0]
+    assert n_hits > 150 and n_ties > 20  # the fixture really exercises hits and in-leaf ties
+
+
+def test_slab_including_nan_order(gold):
+    o = gold["slab_origin"].reshape(-1, 3)
+    d = gold["slab_dir"].reshape(-1, 3)
+    mn = gold["slab_min"].reshape(-1, 3)
+    mx = gold["slab_max"].reshape(-1, 3)
+    want = gold["slab_hit"]
+    got = np.array([orc.lib.orc_slab(np.ascontiguousarray(o[q]), np.ascontiguousarray(d[q]),
+                                     np.ascontiguousarray(mn[q]), np.ascontiguousarray(mx[q]))
+                    for q in range(o.shape[0])])
+    assert np.array_equal(got, want)
+    # the fixture contains genuinely NaN-producing cases (0 * inf) on both outcomes
+    nan_cases = np.isnan(gold["slab_tmin"]) | np.isnan(gold["slab_tmax"])
+    assert nan_cases.sum() > 20
+    assert 0 < want.sum() < want.size
+
+
+def test_shading_and_quantise(gold):
+    bary = gold["shade_bary"].reshape(-1, 3)
+    fc = gold["shade_fc"].reshape(-1, 3)
+    for q in range(bary.shape[0]):
+        out = np.empty(3)
+        orc.lib.orc_shade_hit(np.ascontiguousarray(bary[q]), np.ascontiguousarray(fc[q]), out)
+        assert np.array_equal(bits(out), bits(gold["shade_hit"].reshape(-1, 3)[q])), q
+        orc.lib.orc_shade_sky(float(gold["shade_diry"][q]), out)
+        assert np.array_equal(bits(out), bits(gold["shade_sky"].reshape(-1, 3)[q])), q
+        inten = orc.C.c_double()
+        byte = orc.lib.orc_quantise(np.ascontiguousarray(gold["quant_pc"].reshape(-1, 3)[q]),
+                                    int(gold["quant_spp"][q]), orc.C.byref(inten))
+        assert byte == int(gold["quant_byte"][q])
+        assert bits([inten.value])[0] == bits([gold["quant_intensity"][q]])[0]
