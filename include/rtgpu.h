@@ -1,0 +1,201 @@
+/*
+ * rtgpu.h -- C ABI of librtgpu.so: the MI355X (gfx950) render hot path of
+ * AnalogArnold/rayTracer behind plain pointers and sizes.
+ *
+ * Every entry point names the reference interface it replaces (paths under the
+ * reference checkout).  All arrays are caller-owned, C-contiguous, IEEE binary64
+ * unless stated.  Functions returning int return 0 on success and a negative
+ * RT_E_* code on failure; rt_last_error() then holds a message (thread-local).
+ * No exceptions cross the ABI.  A context is bound to one GPU and may be used by
+ * one host thread at a time.  There is no CPU fallback: without a GPU, or without
+ * the HIP runtime, the device entry points fail with RT_E_NO_DEVICE.
+ */
+#ifndef RTGPU_H
+#define RTGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_OK 0
+#define RT_E_INVALID (-1)   /* bad argument */
+#define RT_E_NO_DEVICE (-2) /* no usable HIP device / HIP call failed */
+#define RT_E_NO_SCENE (-3)  /* render before rt_upload_scene */
+#define RT_E_IO (-4)        /* cannot open output file */
+#define RT_E_LIMIT (-5)     /* scene exceeds an encoding limit */
+#define RT_E_NOMEM (-6)
+
+typedef struct rt_ctx rt_ctx;     /* device context: one per GPU */
+typedef struct rt_scene rt_scene; /* host-side acceleration structure of ONE timestep, flattened */
+
+const char *rt_last_error(void);
+const char *rt_version(void);
+int rt_device_count(void);
+
+/* ------------------------------------------------------------------ */
+/* Host BVH build + flatten.                                           */
+/* Replaces: TLAS build_acceleration_structures(coords, colours,      */
+/*   timestep, timestep_count)  cpp/rtbvh.h:235-238, rtbvh.cpp:590-685 */
+/* (binned SAH, 8 bins, BLAS leaf <= 4, TLAS leaf <= 2; tree identical */
+/* to the reference's, node for node).                                 */
+/*   coords[m]  : (T, E_m, 3, 3)   colors[m] : (T, E_m, 3)             */
+/*   elem_counts[m] = E_m (the reference reads it from                 */
+/*   face_colors.shape(1), rtbvh.cpp:615).  E_m >= 1.                  */
+/* n_threads: meshes are built concurrently on up to n_threads host    */
+/* threads (<= 0: one per mesh, capped at 16); results do not depend   */
+/* on it.                                                              */
+/* ------------------------------------------------------------------ */
+rt_scene *rt_scene_build(int n_meshes, const double *const *coords, const double *const *colors,
+                         const int64_t *elem_counts, int timestep, int n_threads);
+void rt_scene_free(rt_scene *scene);
+
+typedef struct {
+    int32_t n_meshes;       /* = number of BLAS slots */
+    int32_t n_tlas_nodes;
+    int64_t n_blas_nodes;   /* sum over slots, reference numbering */
+    int64_t n_tris;         /* sum over meshes */
+    int64_t n_dev_nodes;    /* records in the device node array (includes alignment pads) */
+    int32_t stack_need;     /* traversal stack entries the kernel needs for this tree */
+    int32_t max_leaf_tris;  /* largest leaf (unbounded when a split fails, rtbvh.cpp:295-297) */
+    int64_t midpoint_fallbacks; /* number of "SAH splitting failed" events, rtbvh.cpp:128 */
+    double build_seconds;
+} rt_scene_info_t;
+int rt_scene_info(const rt_scene *scene, rt_scene_info_t *out);
+
+/* Introspection of the host tree in the reference's own numbering (parity tests). */
+int rt_scene_tlas(const rt_scene *scene, double *boxes6, int32_t *blas_count, int32_t *left,
+                  int32_t *min_blas_idx);
+/* slot = position in tlas.blases as the reference stores it (rtbvh.cpp:544-561) */
+int rt_scene_slot_info(const rt_scene *scene, int slot, int32_t *mesh, int32_t *n_nodes, int32_t *n_elems,
+                       int64_t *tri_base);
+int rt_scene_slot_nodes(const rt_scene *scene, int slot, double *boxes6, int32_t *left, int64_t *count,
+                        int32_t *min_idx);
+int rt_scene_slot_indices(const rt_scene *scene, int slot, int32_t *sorted_to_elem);
+/* prim id (as returned by the kernels) -> (mesh, element); arrays of n_tris */
+int rt_scene_prim_tables(const rt_scene *scene, int32_t *prim_mesh, int32_t *prim_elem);
+
+/* ------------------------------------------------------------------ */
+/* Device context                                                      */
+/* ------------------------------------------------------------------ */
+rt_ctx *rt_create(int device);
+void rt_destroy(rt_ctx *ctx);
+/* Upload the flattened tree (once per frame/timestep; replaces the TLAS by-value
+ * local of cpp/rtmain.cpp:50 as the thing render_ppm_image reads). */
+int rt_upload_scene(rt_ctx *ctx, const rt_scene *scene);
+
+/* ------------------------------------------------------------------ */
+/* Sampler: the reference's process-global `static std::mt19937        */
+/* generator` (seed 5489, never reseeded) + uniform_real_distribution  */
+/* cpp/rtmathutils.h:15-19.  The context keeps the stream position in  */
+/* 32-bit outputs; rt_render() consumes H*W*spp*4 words per full image */
+/* exactly like render_ppm_image does.  Jitter pairs are generated on  */
+/* the GPU from jump-ahead states (GF(2) polynomial jump on the host). */
+/* ------------------------------------------------------------------ */
+int rt_rng_seed(rt_ctx *ctx, uint32_t seed);          /* position 0 of mt19937(seed) */
+int rt_rng_seek(rt_ctx *ctx, uint64_t word_position); /* absolute position in the seeded stream */
+uint64_t rt_rng_tell(const rt_ctx *ctx);
+/* Test seam: the next n values random_double()-0.5 would return, generated on the
+ * GPU by the same kernel rt_render uses, in `n_streams` jump-ahead streams.  Advances
+ * the position by 2*n words. */
+int rt_rng_jitter(rt_ctx *ctx, int64_t n, int n_streams, double *out_host);
+/* Host-only helpers (no GPU needed): the raw 624-word generator state that precedes
+ * `word_position` of mt19937(seed), and n such states `stride` words apart.  The state is
+ * the window x[p-624..p-1] of untempered words; the bits of the oldest word below bit 31
+ * are not part of the generator's state and are unspecified. */
+int rt_mt19937_state_at(uint32_t seed, uint64_t word_position, uint32_t *state624);
+int rt_mt19937_stream_states(uint32_t seed, uint64_t base_position, uint64_t stride, int n,
+                             uint32_t *states);
+
+/* ------------------------------------------------------------------ */
+/* Render one image (or a band of its rows).                           */
+/* Replaces the body of render_ppm_image(...)  cpp/rtrender.h:22-29,   */
+/* rtrender.cpp:35-67 (everything but the file write) and its callees  */
+/* return_ray_color / intersect_TLAS / intersect_BLAS / intersect_AABB */
+/* / intersect_bvh_triangles  (rtrender.cpp:13-33,                     */
+/* rtrayintersection.cpp:36-228).                                      */
+/* ------------------------------------------------------------------ */
+#define RT_SAMPLER_MT19937 0  /* reference stream from the context's position */
+#define RT_SAMPLER_EXPLICIT 1 /* caller supplies the (ox, oy) offsets */
+
+#define RT_FLAG_HIT_IDS 1u  /* keep per-sample prim ids (int32, -1 = miss) */
+#define RT_FLAG_COUNTERS 2u /* count nodes/triangles visited (slower; for the roofline model) */
+#define RT_FLAG_HIT_T 4u    /* keep per-sample closest t (f64, +inf = miss) */
+
+typedef struct {
+    double camera_center[3];
+    double pixel_00_center[3];
+    double pixel_spacing[6]; /* 2x3 row-major */
+    int32_t image_height, image_width, samples;
+    int32_t row_begin, row_end; /* rows [row_begin,row_end) are rendered; 0,H for the whole image */
+    int32_t sampler;
+    uint32_t flags;
+    /* RT_SAMPLER_EXPLICIT: host array of (row_end-row_begin)*W*spp pairs, sample order (j,i,k) */
+    const double *jitter;
+} rt_render_params;
+
+/* Results stay in context-owned device buffers until rt_download / the next rt_render.
+ * With RT_SAMPLER_MT19937 the stream position advances by (row_end-row_begin)*W*spp*4;
+ * rows before row_begin are NOT skipped automatically (callers that shard an image by
+ * row bands seek to frame_base + row_begin*W*spp*4 themselves). */
+int rt_render(rt_ctx *ctx, const rt_render_params *params);
+
+/* Copy results of the last rt_render to host; any pointer may be NULL.
+ *   intensity: rows*W  f64  gray/spp before quantisation (rtrender.cpp:61-62)
+ *   rgb      : rows*W*3 u8  the P6 payload (rtrender.cpp:63-65)
+ *   hit_prim : rows*W*spp i32, needs RT_FLAG_HIT_IDS
+ *   hit_t    : rows*W*spp f64, needs RT_FLAG_HIT_T */
+int rt_download(rt_ctx *ctx, double *intensity, uint8_t *rgb, int32_t *hit_prim, double *hit_t);
+
+typedef struct {
+    double render_kernel_ms; /* HIP-event time of the traversal kernel, on its own stream */
+    double jitter_kernel_ms; /* HIP-event time of the MT19937 jitter kernel */
+    double host_jump_ms;     /* host time spent on jump-ahead states */
+    uint64_t rays;
+    uint64_t nodes_visited; /* RT_FLAG_COUNTERS: TLAS+BLAS nodes slab-tested */
+    uint64_t tris_tested;   /* RT_FLAG_COUNTERS */
+    uint64_t rays_hit;      /* RT_FLAG_COUNTERS */
+} rt_stats;
+int rt_last_stats(const rt_ctx *ctx, rt_stats *out);
+int rt_sync(rt_ctx *ctx);
+
+/* Raw device pointers of the last render's outputs (for callers that keep the
+ * framebuffer on the GPU, e.g. a peer gather).  NULL if not produced. */
+int rt_device_outputs(rt_ctx *ctx, void **intensity, void **rgb, void **hit_prim);
+
+/* ------------------------------------------------------------------ */
+/* Arbitrary rays against the uploaded scene.                          */
+/* Test seam for return_ray_color(ray, TLAS) cpp/rtrender.h:19-20 and  */
+/* intersect_TLAS  cpp/rtrayintersection.h:34-37.  dirs are used as    */
+/* given (not normalised).  Outputs may be NULL.                       */
+/* ------------------------------------------------------------------ */
+int rt_trace_rays(rt_ctx *ctx, int64_t n, const double *origins, const double *dirs, double *t,
+                  double *bary_uvw, double *color, int32_t *prim);
+
+/* ------------------------------------------------------------------ */
+/* Whole-job driver.                                                   */
+/* Replaces render_scene(...) cpp/rtmain.cpp:29-73 == the nanobind     */
+/* export cpp_render_scene (rtmain.cpp:157-160): for each timestep     */
+/* build+upload, for each camera render and write                      */
+/* <dir>/rtimage_<t>_cam<c>.ppm, printing the reference's stdout lines.*/
+/* The sampler stream is process-global and never reseeded, like the   */
+/* reference's static generator.                                       */
+/* rank/world shard frames f = t*n_cameras + c with f % world == rank  */
+/* (no collective; every rank seeks the stream to its frame).          */
+/* ------------------------------------------------------------------ */
+int rt_render_scene(int image_height, int image_width, int number_of_samples, const char *output_directory,
+                    int timestep_count, int n_meshes, const double *const *coords,
+                    const double *const *colors, const int64_t *elem_counts, int n_cameras,
+                    const double *camera_centers, const double *pixel_00_centers,
+                    const double *pixel_spacings, int device, int rank, int world);
+
+/* P6 writer: "P6\nW H\n255\n" + payload (rtrender.cpp:69-81). Prints the
+ * reference's messages ("Failed to open the output file." / " Done."). */
+int rt_write_ppm(const char *path, int width, int height, const uint8_t *rgb);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTGPU_H */

@@ -1,0 +1,214 @@
+"""Thin object layer over the C ABI (include/rtgpu.h): HostScene (built tree) and Context (one GPU)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from ._lib import lib
+
+
+def _mesh_arrays(coords, colors):
+    coords = [L.f64(c) for c in coords]
+    colors = [L.f64(c) for c in colors]
+    if len(coords) != len(colors) or not coords:
+        raise ValueError("need the same, non-zero number of coordinate and colour arrays")
+    for m, (c, k) in enumerate(zip(coords, colors)):
+        # the reference takes E from face_colors.shape(1) (cpp/rtbvh.cpp:615): (T,E,3,3) / (T,E,3)
+        if c.ndim != 4 or c.shape[2:] != (3, 3) or k.ndim != 3 or k.shape[2] != 3:
+            raise ValueError(f"mesh {m}: expected coords (T,E,3,3) and colours (T,E,3), got {c.shape} / {k.shape}")
+        if c.shape[:2] != k.shape[:2]:
+            raise ValueError(f"mesh {m}: coords {c.shape} and colours {k.shape} disagree on (T,E)")
+    n = len(coords)
+    cp = (C.c_void_p * n)(*[c.ctypes.data for c in coords])
+    kp = (C.c_void_p * n)(*[k.ctypes.data for k in colors])
+    counts = np.array([k.shape[1] for k in colors], np.int64)
+    return coords, colors, cp, kp, counts
+
+
+class HostScene:
+    """Acceleration structure of one timestep, built on the host exactly as the reference's
+    build_acceleration_structures (cpp/rtbvh.cpp:590-685) and flattened for the GPU."""
+
+    def __init__(self, coords, colors, timestep=0, n_threads=0):
+        self._keep = _mesh_arrays(coords, colors)
+        coords, colors, cp, kp, counts = self._keep
+        T = coords[0].shape[0]
+        if not 0 <= timestep < T:
+            raise ValueError(f"timestep {timestep} outside [0,{T})")
+        self.h = lib.rt_scene_build(len(coords), cp, kp, L.ptr(counts), int(timestep), int(n_threads))
+        if not self.h:
+            raise L.RtError(lib.rt_last_error().decode())
+        info = L.SceneInfo()
+        L.check(lib.rt_scene_info(self.h, C.byref(info)), "rt_scene_info")
+        self.info = info
+        self._prim = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib.rt_scene_free(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def tlas(self):
+        n = self.info.n_tlas_nodes
+        boxes = np.empty((n, 6))
+        cnt, left, mn = (np.empty(n, np.int32) for _ in range(3))
+        L.check(lib.rt_scene_tlas(self.h, L.ptr(boxes), L.ptr(cnt), L.ptr(left), L.ptr(mn)), "rt_scene_tlas")
+        return dict(boxes=boxes, blas_count=cnt, left=left, min_blas_idx=mn)
+
+    def slot(self, s):
+        mesh, nn, ne, tb = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int64()
+        L.check(lib.rt_scene_slot_info(self.h, s, C.byref(mesh), C.byref(nn), C.byref(ne), C.byref(tb)),
+                "rt_scene_slot_info")
+        boxes = np.empty((nn.value, 6))
+        left = np.empty(nn.value, np.int32)
+        count = np.empty(nn.value, np.int64)
+        min_idx = np.empty(nn.value, np.int32)
+        L.check(lib.rt_scene_slot_nodes(self.h, s, L.ptr(boxes), L.ptr(left), L.ptr(count), L.ptr(min_idx)),
+                "rt_scene_slot_nodes")
+        idx = np.empty(ne.value, np.int32)
+        L.check(lib.rt_scene_slot_indices(self.h, s, L.ptr(idx)), "rt_scene_slot_indices")
+        return dict(mesh=mesh.value, boxes=boxes, left=left, count=count, min_idx=min_idx, indices=idx,
+                    tri_base=tb.value)
+
+    def prim_tables(self):
+        """prim id -> (mesh index, element index)."""
+        if self._prim is None:
+            n = self.info.n_tris
+            pm, pe = np.empty(n, np.int32), np.empty(n, np.int32)
+            L.check(lib.rt_scene_prim_tables(self.h, L.ptr(pm), L.ptr(pe)), "rt_scene_prim_tables")
+            self._prim = (pm, pe)
+        return self._prim
+
+    def map_prims(self, prim):
+        """Per-sample prim ids -> (mesh, elem) arrays, -1 for misses."""
+        pm, pe = self.prim_tables()
+        prim = np.asarray(prim)
+        hit = prim >= 0
+        mesh = np.full(prim.shape, -1, np.int32)
+        elem = np.full(prim.shape, -1, np.int32)
+        mesh[hit] = pm[prim[hit]]
+        elem[hit] = pe[prim[hit]]
+        return mesh, elem
+
+
+class Context:
+    """One GPU.  Raises if no HIP device is usable: there is no CPU path."""
+
+    def __init__(self, device=0):
+        self.h = lib.rt_create(int(device))
+        if not self.h:
+            raise L.RtError(lib.rt_last_error().decode())
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib.rt_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def upload(self, scene: HostScene):
+        L.check(lib.rt_upload_scene(self.h, scene.h), "rt_upload_scene")
+
+    # ---- sampler ----
+    def rng_seed(self, seed=5489):
+        L.check(lib.rt_rng_seed(self.h, seed), "rt_rng_seed")
+
+    def rng_seek(self, pos):
+        L.check(lib.rt_rng_seek(self.h, int(pos)), "rt_rng_seek")
+
+    def rng_tell(self):
+        return int(lib.rt_rng_tell(self.h))
+
+    def rng_jitter(self, n, n_streams=4):
+        out = np.empty(int(n), np.float64)
+        L.check(lib.rt_rng_jitter(self.h, int(n), int(n_streams), L.ptr(out)), "rt_rng_jitter")
+        return out
+
+    # ---- render ----
+    def render(self, cam, p00, spacing, H, W, spp, *, rows=None, jitter=None, hit_ids=False, hit_t=False,
+               counters=False):
+        p = L.RenderParams()
+        p.camera_center[:] = list(L.f64(cam, 3))
+        p.pixel_00_center[:] = list(L.f64(p00, 3))
+        p.pixel_spacing[:] = list(L.f64(spacing, 6))
+        p.image_height, p.image_width, p.samples = int(H), int(W), int(spp)
+        p.row_begin, p.row_end = (0, int(H)) if rows is None else (int(rows[0]), int(rows[1]))
+        p.flags = (L.RT_FLAG_HIT_IDS if hit_ids else 0) | (L.RT_FLAG_HIT_T if hit_t else 0) | (
+            L.RT_FLAG_COUNTERS if counters else 0)
+        keep = None
+        if jitter is not None:
+            keep = L.f64(jitter).reshape(-1)
+            need = (p.row_end - p.row_begin) * W * spp * 2
+            if keep.size != need:
+                raise ValueError(f"jitter needs {need} values, got {keep.size}")
+            p.sampler = L.RT_SAMPLER_EXPLICIT
+            p.jitter = keep.ctypes.data
+        else:
+            p.sampler = L.RT_SAMPLER_MT19937
+        L.check(lib.rt_render(self.h, C.byref(p)), "rt_render")
+        self._shape = (p.row_end - p.row_begin, int(W), int(spp))
+        self._flags = p.flags
+
+    def download(self, intensity=True, rgb=True, hit_ids=None, hit_t=None):
+        rows, W, spp = self._shape
+        hit_ids = bool(self._flags & L.RT_FLAG_HIT_IDS) if hit_ids is None else hit_ids
+        hit_t = bool(self._flags & L.RT_FLAG_HIT_T) if hit_t is None else hit_t
+        out = {}
+        a = np.empty((rows, W)) if intensity else None
+        b = np.empty((rows, W, 3), np.uint8) if rgb else None
+        c = np.empty(rows * W * spp, np.int32) if hit_ids else None
+        d = np.empty(rows * W * spp) if hit_t else None
+        L.check(lib.rt_download(self.h, L.ptr(a), L.ptr(b), L.ptr(c), L.ptr(d)), "rt_download")
+        if a is not None:
+            out["intensity"] = a
+        if b is not None:
+            out["rgb"] = b
+        if c is not None:
+            out["hit_prim"] = c
+        if d is not None:
+            out["hit_t"] = d
+        return out
+
+    def stats(self):
+        s = L.Stats()
+        L.check(lib.rt_last_stats(self.h, C.byref(s)), "rt_last_stats")
+        return {k: getattr(s, k) for k, _ in s._fields_}
+
+    def sync(self):
+        L.check(lib.rt_sync(self.h), "rt_sync")
+
+    def trace(self, origins, dirs):
+        o = L.f64(origins).reshape(-1, 3)
+        d = L.f64(dirs).reshape(-1, 3)
+        n = o.shape[0]
+        if d.shape[0] != n:
+            raise ValueError("origins and dirs differ in length")
+        t = np.empty(n)
+        bary = np.empty((n, 3))
+        col = np.empty((n, 3))
+        prim = np.empty(n, np.int32)
+        L.check(lib.rt_trace_rays(self.h, n, L.ptr(o), L.ptr(d), L.ptr(t), L.ptr(bary), L.ptr(col), L.ptr(prim)),
+                "rt_trace_rays")
+        return dict(t=t, bary=bary, color=col, prim=prim)
+
+
+def mt19937_state_at(pos, seed=5489):
+    out = np.empty(624, np.uint32)
+    L.check(lib.rt_mt19937_state_at(seed, int(pos), L.ptr(out)), "rt_mt19937_state_at")
+    return out
+
+
+def mt19937_stream_states(base, stride, n, seed=5489):
+    out = np.empty((n, 624), np.uint32)
+    L.check(lib.rt_mt19937_stream_states(seed, int(base), int(stride), int(n), L.ptr(out)),
+            "rt_mt19937_stream_states")
+    return out
+
+
+def write_ppm(path, rgb):
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    h, w = rgb.shape[:2]
+    L.check(lib.rt_write_ppm(str(path).encode(), w, h, L.ptr(rgb)), "rt_write_ppm")

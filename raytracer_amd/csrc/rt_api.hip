@@ -1,0 +1,838 @@
+// rt_api.hip -- C ABI of librtgpu.so (see include/rtgpu.h): contexts, uploads, launches,
+// the MT19937 stream bookkeeping and the whole-job driver.  Host + device in one TU so the
+// kernels can be launched with <<<>>>; compiled for gfx950 only, -ffp-contract=off.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/rtgpu.h"
+#include "rt_bvh.hpp"
+#include "rt_kernels.hip.hpp"
+#include "rt_mt19937.hpp"
+
+struct rt_scene {
+    std::unique_ptr<rt::Scene> s;
+};
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(RT_E_NO_DEVICE, std::string(#expr) + " failed: " + hipGetErrorString(e_)); \
+    } while (0)
+
+double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+int host_threads() {
+    const char* e = std::getenv("RT_HOST_THREADS");
+    int n = e ? std::atoi(e) : 0;
+    if (n <= 0) {
+        const char* omp = std::getenv("OMP_NUM_THREADS");
+        n = omp ? std::atoi(omp) : 0;
+    }
+    if (n <= 0) n = 8;
+    return std::min(n, 64);
+}
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;  // elements
+    int ensure(size_t n) {
+        if (n <= cap) return RT_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(n, 1) * sizeof(T));
+        if (e != hipSuccess) {
+            p = nullptr;
+            return fail(RT_E_NOMEM, std::string("hipMalloc failed: ") + hipGetErrorString(e));
+        }
+        cap = n;
+        return RT_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+}  // namespace
+
+struct rt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;      // traversal kernels
+    hipStream_t rng_stream = nullptr;  // jitter kernel (overlaps the previous band's traversal)
+    hipEvent_t ev[6] = {};             // 0/1 render start/stop, 2/3 jitter start/stop, 4 jitter done, 5 render done
+    // scene
+    bool have_scene = false;
+    DevBuf<rt::DevNode> nodes, tlas;
+    DevBuf<int32_t> slot_root;
+    DevBuf<uint32_t> leaf_ext;
+    DevBuf<double> tris, colors;
+    int32_t stack_need = 1;
+    int64_t n_tris = 0;
+    // sampler
+    uint32_t seed = 5489u;
+    uint64_t pos = 0;   // position of the global stream, in 32-bit outputs
+    rt::MtState state;  // state preceding `pos`
+    // look-ahead: stream states computed for a predicted next call while the GPU is busy
+    struct Prefetch {
+        bool valid = false;
+        uint64_t pos = 0, stride = 0;
+        int n = 0;
+        std::vector<rt::MtState> states;
+        rt::MtState end_state;  // state preceding pos + total_words
+        uint64_t total_words = 0;
+    } pre;
+    DevBuf<uint32_t> d_states;
+    DevBuf<double> jitter;
+    // outputs of the last render
+    DevBuf<double> intensity, hit_t;
+    DevBuf<uint8_t> rgb;
+    DevBuf<int32_t> hit_prim;
+    DevBuf<unsigned long long> counters;
+    DevBuf<uint32_t> gstack;
+    int32_t out_rows = 0, out_w = 0, out_spp = 0;
+    uint32_t out_flags = 0;
+    bool timing_pending = false, jitter_timed = false;
+    rt_stats stats{};
+    // scratch for rt_trace_rays
+    DevBuf<double> tr_o, tr_d, tr_t, tr_b, tr_c;
+    DevBuf<int32_t> tr_p;
+};
+
+namespace {
+
+rtk::DevScene dev_scene(const rt_ctx* c) {
+    rtk::DevScene d;
+    d.nodes = c->nodes.p;
+    d.tlas = c->tlas.p;
+    d.slot_root = c->slot_root.p;
+    d.leaf_ext = c->leaf_ext.p;
+    d.tris = c->tris.p;
+    d.colors = c->colors.p;
+    return d;
+}
+
+// Smallest LDS stack variant that holds the tree's need; 0 = global-memory stack.
+int pick_stack(int need) {
+    if (need <= 16) return 16;
+    if (need <= 24) return 24;
+    if (need <= 32) return 32;
+    if (need <= 48) return 48;
+    return 0;
+}
+
+template <bool COUNT>
+void launch_render(int stack, dim3 grid, hipStream_t st, const rtk::RenderArgs& a) {
+    switch (stack) {
+        case 16: hipLaunchKernelGGL((rtk::render_kernel<16, COUNT>), grid, dim3(rtk::NT), 0, st, a); break;
+        case 24: hipLaunchKernelGGL((rtk::render_kernel<24, COUNT>), grid, dim3(rtk::NT), 0, st, a); break;
+        case 32: hipLaunchKernelGGL((rtk::render_kernel<32, COUNT>), grid, dim3(rtk::NT), 0, st, a); break;
+        case 48: hipLaunchKernelGGL((rtk::render_kernel<48, COUNT>), grid, dim3(rtk::NT), 0, st, a); break;
+        default: hipLaunchKernelGGL((rtk::render_kernel<0, COUNT>), grid, dim3(rtk::NT), 0, st, a); break;
+    }
+}
+
+void launch_trace(int stack, dim3 grid, hipStream_t st, const rtk::TraceArgs& a) {
+    switch (stack) {
+        case 16: hipLaunchKernelGGL((rtk::trace_kernel<16>), grid, dim3(rtk::NT), 0, st, a); break;
+        case 24: hipLaunchKernelGGL((rtk::trace_kernel<24>), grid, dim3(rtk::NT), 0, st, a); break;
+        case 32: hipLaunchKernelGGL((rtk::trace_kernel<32>), grid, dim3(rtk::NT), 0, st, a); break;
+        case 48: hipLaunchKernelGGL((rtk::trace_kernel<48>), grid, dim3(rtk::NT), 0, st, a); break;
+        default: hipLaunchKernelGGL((rtk::trace_kernel<0>), grid, dim3(rtk::NT), 0, st, a); break;
+    }
+}
+
+// Streams of one jitter launch: rows are split into n groups of R rows; stream g covers rows
+// [g*R, (g+1)*R) and starts `stride` = R*W*spp*4 words after stream g-1.
+struct StreamPlan {
+    int n = 1;
+    uint64_t stride = 0;       // words
+    uint64_t total_words = 0;  // rows*W*spp*4
+};
+
+StreamPlan plan_streams(int rows, int W, int spp) {
+    StreamPlan p;
+    // at most 256 streams (one wave each), and no stream shorter than 2^18 words: the host
+    // pays one polynomial jump (~3 ms) per stream
+    const uint64_t words = uint64_t(rows) * uint64_t(W) * uint64_t(spp) * 4u;
+    int target = (int)std::min<uint64_t>(256, std::max<uint64_t>(1, words >> 18));
+    if (const char* e = std::getenv("RT_JITTER_STREAMS")) target = std::max(1, std::atoi(e));
+    const int R = std::max(1, (rows + target - 1) / target);
+    p.n = (rows + R - 1) / R;
+    p.stride = uint64_t(R) * uint64_t(W) * uint64_t(spp) * 4u;
+    p.total_words = uint64_t(rows) * uint64_t(W) * uint64_t(spp) * 4u;
+    return p;
+}
+
+void compute_states(const rt::MtState& base, const StreamPlan& pl, std::vector<rt::MtState>& states,
+                    rt::MtState& end_state) {
+    rt::mt_stream_states(base, pl.stride, pl.n, host_threads(), states);
+    // state after the whole launch: jump from the last stream's start by the remainder
+    const uint64_t rem = pl.total_words - uint64_t(pl.n - 1) * pl.stride;
+    rt::mt_apply(rt::mt_jump_poly(rem), states[pl.n - 1], end_state);
+}
+
+int launch_jitter(rt_ctx* c, const std::vector<rt::MtState>& states, const StreamPlan& pl, double* d_out,
+                  hipStream_t st) {
+    int rc = c->d_states.ensure(size_t(pl.n) * rt::MT_N);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(c->d_states.p, states.data(), size_t(pl.n) * sizeof(rt::MtState), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(rtk::mt_jitter_kernel, dim3(pl.n), dim3(64), 0, st, c->d_states.p, d_out,
+                       (unsigned long long)(pl.stride / 2), (unsigned long long)(pl.total_words / 2));
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+std::mutex g_global_mu;
+rt_ctx* g_global_ctx[64] = {};
+
+}  // namespace
+
+extern "C" {
+
+const char* rt_last_error(void) { return g_err.c_str(); }
+const char* rt_version(void) { return "rtgpu 0.1 (gfx950, fp64 parity path)"; }
+
+int rt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+/* ------------------------------------------------------------------ host scene */
+rt_scene* rt_scene_build(int n_meshes, const double* const* coords, const double* const* colors,
+                         const int64_t* elem_counts, int timestep, int n_threads) {
+    try {
+        if (!coords || !colors || !elem_counts) {
+            g_err = "rt_scene_build: null argument";
+            return nullptr;
+        }
+        std::unique_ptr<rt_scene> h(new rt_scene());
+        h->s.reset(rt::build_scene(n_meshes, coords, colors, elem_counts, timestep, n_threads));
+        return h.release();
+    } catch (const std::exception& e) {
+        g_err = std::string("rt_scene_build: ") + e.what();
+        return nullptr;
+    }
+}
+
+void rt_scene_free(rt_scene* scene) { delete scene; }
+
+int rt_scene_info(const rt_scene* scene, rt_scene_info_t* out) {
+    if (!scene || !out) return fail(RT_E_INVALID, "rt_scene_info: null argument");
+    const rt::Scene& s = *scene->s;
+    out->n_meshes = (int32_t)s.slots.size();
+    out->n_tlas_nodes = (int32_t)s.tlas.size();
+    out->n_blas_nodes = s.n_blas_nodes;
+    out->n_tris = (int64_t)s.prim_mesh.size();
+    out->n_dev_nodes = (int64_t)s.dev_nodes.size();
+    out->stack_need = s.stack_need;
+    out->max_leaf_tris = s.max_leaf_tris;
+    out->midpoint_fallbacks = s.midpoint_fallbacks;
+    out->build_seconds = s.build_seconds;
+    return RT_OK;
+}
+
+int rt_scene_tlas(const rt_scene* scene, double* boxes6, int32_t* blas_count, int32_t* left, int32_t* min_blas_idx) {
+    if (!scene) return fail(RT_E_INVALID, "rt_scene_tlas: null scene");
+    const rt::Scene& s = *scene->s;
+    for (size_t i = 0; i < s.tlas.size(); ++i) {
+        if (boxes6) {
+            std::memcpy(boxes6 + 6 * i, s.tlas[i].mn, 3 * sizeof(double));
+            std::memcpy(boxes6 + 6 * i + 3, s.tlas[i].mx, 3 * sizeof(double));
+        }
+        if (blas_count) blas_count[i] = (int32_t)s.tlas[i].count;
+        if (left) left[i] = s.tlas[i].left;
+        if (min_blas_idx) min_blas_idx[i] = s.tlas[i].first;
+    }
+    return RT_OK;
+}
+
+int rt_scene_slot_info(const rt_scene* scene, int slot, int32_t* mesh, int32_t* n_nodes, int32_t* n_elems,
+                       int64_t* tri_base) {
+    if (!scene) return fail(RT_E_INVALID, "rt_scene_slot_info: null scene");
+    const rt::Scene& s = *scene->s;
+    if (slot < 0 || slot >= (int)s.slots.size()) return fail(RT_E_INVALID, "rt_scene_slot_info: bad slot");
+    if (mesh) *mesh = s.slots[slot].mesh;
+    if (n_nodes) *n_nodes = (int32_t)s.slots[slot].nodes.size();
+    if (n_elems) *n_elems = (int32_t)s.slots[slot].sorted_to_elem.size();
+    if (tri_base) *tri_base = s.slot_tri_base[slot];
+    return RT_OK;
+}
+
+int rt_scene_slot_nodes(const rt_scene* scene, int slot, double* boxes6, int32_t* left, int64_t* count,
+                        int32_t* min_idx) {
+    if (!scene) return fail(RT_E_INVALID, "rt_scene_slot_nodes: null scene");
+    const rt::Scene& s = *scene->s;
+    if (slot < 0 || slot >= (int)s.slots.size()) return fail(RT_E_INVALID, "rt_scene_slot_nodes: bad slot");
+    const auto& nodes = s.slots[slot].nodes;
+    for (size_t i = 0; i < nodes.size(); ++i) {
+        if (boxes6) {
+            std::memcpy(boxes6 + 6 * i, nodes[i].mn, 3 * sizeof(double));
+            std::memcpy(boxes6 + 6 * i + 3, nodes[i].mx, 3 * sizeof(double));
+        }
+        if (left) left[i] = nodes[i].left;
+        if (count) count[i] = nodes[i].count;
+        if (min_idx) min_idx[i] = nodes[i].first;
+    }
+    return RT_OK;
+}
+
+int rt_scene_slot_indices(const rt_scene* scene, int slot, int32_t* sorted_to_elem) {
+    if (!scene || !sorted_to_elem) return fail(RT_E_INVALID, "rt_scene_slot_indices: null argument");
+    const rt::Scene& s = *scene->s;
+    if (slot < 0 || slot >= (int)s.slots.size()) return fail(RT_E_INVALID, "rt_scene_slot_indices: bad slot");
+    const auto& v = s.slots[slot].sorted_to_elem;
+    std::memcpy(sorted_to_elem, v.data(), v.size() * sizeof(int32_t));
+    return RT_OK;
+}
+
+int rt_scene_prim_tables(const rt_scene* scene, int32_t* prim_mesh, int32_t* prim_elem) {
+    if (!scene) return fail(RT_E_INVALID, "rt_scene_prim_tables: null scene");
+    const rt::Scene& s = *scene->s;
+    if (prim_mesh) std::memcpy(prim_mesh, s.prim_mesh.data(), s.prim_mesh.size() * sizeof(int32_t));
+    if (prim_elem) std::memcpy(prim_elem, s.prim_elem.data(), s.prim_elem.size() * sizeof(int32_t));
+    return RT_OK;
+}
+
+/* ------------------------------------------------------------------ sampler (host part) */
+int rt_mt19937_state_at(uint32_t seed, uint64_t word_position, uint32_t* state624) {
+    if (!state624) return fail(RT_E_INVALID, "rt_mt19937_state_at: null output");
+    try {
+        rt::MtState s, o;
+        rt::mt_seed(s, seed);
+        rt::mt_apply(rt::mt_jump_poly(word_position), s, o);
+        std::memcpy(state624, o.w, sizeof(o.w));
+        return RT_OK;
+    } catch (const std::exception& e) {
+        return fail(RT_E_INVALID, e.what());
+    }
+}
+
+int rt_mt19937_stream_states(uint32_t seed, uint64_t base_position, uint64_t stride, int n, uint32_t* states) {
+    if (!states || n < 1) return fail(RT_E_INVALID, "rt_mt19937_stream_states: bad argument");
+    try {
+        rt::MtState s, b;
+        rt::mt_seed(s, seed);
+        rt::mt_apply(rt::mt_jump_poly(base_position), s, b);
+        std::vector<rt::MtState> out;
+        rt::mt_stream_states(b, stride, n, host_threads(), out);
+        std::memcpy(states, out.data(), size_t(n) * sizeof(rt::MtState));
+        return RT_OK;
+    } catch (const std::exception& e) {
+        return fail(RT_E_INVALID, e.what());
+    }
+}
+
+/* ------------------------------------------------------------------ context */
+rt_ctx* rt_create(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        g_err = "rt_create: no HIP device available (this library has no CPU fallback)";
+        return nullptr;
+    }
+    if (device < 0 || device >= n) {
+        g_err = "rt_create: device index out of range";
+        return nullptr;
+    }
+    if (hipSetDevice(device) != hipSuccess) {
+        g_err = "rt_create: hipSetDevice failed";
+        return nullptr;
+    }
+    std::unique_ptr<rt_ctx> c(new rt_ctx());
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->rng_stream, hipStreamNonBlocking) != hipSuccess) {
+        g_err = "rt_create: hipStreamCreate failed";
+        return nullptr;
+    }
+    for (auto& ev : c->ev)
+        if (hipEventCreate(&ev) != hipSuccess) {
+            g_err = "rt_create: hipEventCreate failed";
+            return nullptr;
+        }
+    rt::mt_seed(c->state, c->seed);
+    c->pos = 0;
+    return c.release();
+}
+
+void rt_destroy(rt_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->rng_stream) (void)hipStreamSynchronize(c->rng_stream);
+    c->nodes.release();
+    c->tlas.release();
+    c->slot_root.release();
+    c->leaf_ext.release();
+    c->tris.release();
+    c->colors.release();
+    c->d_states.release();
+    c->jitter.release();
+    c->intensity.release();
+    c->hit_t.release();
+    c->rgb.release();
+    c->hit_prim.release();
+    c->counters.release();
+    c->gstack.release();
+    c->tr_o.release();
+    c->tr_d.release();
+    c->tr_t.release();
+    c->tr_b.release();
+    c->tr_c.release();
+    c->tr_p.release();
+    for (auto& ev : c->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->rng_stream) (void)hipStreamDestroy(c->rng_stream);
+    delete c;
+}
+
+int rt_sync(rt_ctx* c) {
+    if (!c) return fail(RT_E_INVALID, "rt_sync: null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->rng_stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+int rt_upload_scene(rt_ctx* c, const rt_scene* scene) {
+    if (!c || !scene) return fail(RT_E_INVALID, "rt_upload_scene: null argument");
+    const rt::Scene& s = *scene->s;
+    HIP_TRY(hipSetDevice(c->device));
+    // the previous frame's kernels may still be reading the old tree
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    int rc;
+    if ((rc = c->nodes.ensure(s.dev_nodes.size()))) return rc;
+    if ((rc = c->tlas.ensure(s.dev_tlas.size()))) return rc;
+    if ((rc = c->slot_root.ensure(s.slot_root.size()))) return rc;
+    if ((rc = c->leaf_ext.ensure(std::max<size_t>(s.leaf_ext.size(), 2)))) return rc;
+    if ((rc = c->tris.ensure(s.tris.size()))) return rc;
+    if ((rc = c->colors.ensure(s.colors.size()))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->nodes.p, s.dev_nodes.data(), s.dev_nodes.size() * sizeof(rt::DevNode),
+                           hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->tlas.p, s.dev_tlas.data(), s.dev_tlas.size() * sizeof(rt::DevNode),
+                           hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->slot_root.p, s.slot_root.data(), s.slot_root.size() * sizeof(int32_t),
+                           hipMemcpyHostToDevice, c->stream));
+    if (!s.leaf_ext.empty())
+        HIP_TRY(hipMemcpyAsync(c->leaf_ext.p, s.leaf_ext.data(), s.leaf_ext.size() * sizeof(uint32_t),
+                               hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->tris.p, s.tris.data(), s.tris.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->colors.p, s.colors.data(), s.colors.size() * sizeof(double), hipMemcpyHostToDevice,
+                           c->stream));
+    // host vectors are pageable: the copies have been staged when the calls return, but the
+    // scene may be freed by the caller right away, so wait for them here.
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->stack_need = s.stack_need;
+    c->n_tris = (int64_t)s.prim_mesh.size();
+    c->have_scene = true;
+    return RT_OK;
+}
+
+/* ------------------------------------------------------------------ sampler (context part) */
+int rt_rng_seed(rt_ctx* c, uint32_t seed) {
+    if (!c) return fail(RT_E_INVALID, "rt_rng_seed: null context");
+    c->seed = seed;
+    rt::mt_seed(c->state, seed);
+    c->pos = 0;
+    c->pre.valid = false;
+    return RT_OK;
+}
+
+int rt_rng_seek(rt_ctx* c, uint64_t word_position) {
+    if (!c) return fail(RT_E_INVALID, "rt_rng_seek: null context");
+    if (word_position == c->pos) return RT_OK;
+    try {
+        if (word_position > c->pos) {
+            rt::MtState o;
+            rt::mt_apply(rt::mt_jump_poly(word_position - c->pos), c->state, o);
+            c->state = o;
+        } else {
+            rt::MtState s, o;
+            rt::mt_seed(s, c->seed);
+            rt::mt_apply(rt::mt_jump_poly(word_position), s, o);
+            c->state = o;
+        }
+    } catch (const std::exception& e) {
+        return fail(RT_E_INVALID, e.what());
+    }
+    c->pos = word_position;
+    return RT_OK;
+}
+
+uint64_t rt_rng_tell(const rt_ctx* c) { return c ? c->pos : 0; }
+
+int rt_rng_jitter(rt_ctx* c, int64_t n, int n_streams, double* out_host) {
+    if (!c || !out_host || n < 1 || n_streams < 1) return fail(RT_E_INVALID, "rt_rng_jitter: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    try {
+        StreamPlan pl;
+        const uint64_t per = (uint64_t(n) + uint64_t(n_streams) - 1) / uint64_t(n_streams);
+        pl.stride = per * 2;
+        pl.n = int((uint64_t(n) + per - 1) / per);
+        pl.total_words = uint64_t(n) * 2;
+        std::vector<rt::MtState> states;
+        rt::MtState end_state;
+        compute_states(c->state, pl, states, end_state);
+        int rc = c->jitter.ensure(size_t(n));
+        if (rc) return rc;
+        rc = launch_jitter(c, states, pl, c->jitter.p, c->rng_stream);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(out_host, c->jitter.p, size_t(n) * sizeof(double), hipMemcpyDeviceToHost, c->rng_stream));
+        HIP_TRY(hipStreamSynchronize(c->rng_stream));
+        c->state = end_state;
+        c->pos += pl.total_words;
+        c->pre.valid = false;
+    } catch (const std::exception& e) {
+        return fail(RT_E_INVALID, e.what());
+    }
+    return RT_OK;
+}
+
+/* ------------------------------------------------------------------ render */
+int rt_render(rt_ctx* c, const rt_render_params* p) {
+    if (!c || !p) return fail(RT_E_INVALID, "rt_render: null argument");
+    if (!c->have_scene) return fail(RT_E_NO_SCENE, "rt_render: no scene uploaded");
+    const int H = p->image_height, W = p->image_width, spp = p->samples;
+    if (H < 1 || W < 1 || spp < 1) return fail(RT_E_INVALID, "rt_render: image size and samples must be >= 1");
+    if (p->row_begin < 0 || p->row_end > H || p->row_begin >= p->row_end)
+        return fail(RT_E_INVALID, "rt_render: bad row range");
+    if (p->sampler != RT_SAMPLER_MT19937 && p->sampler != RT_SAMPLER_EXPLICIT)
+        return fail(RT_E_INVALID, "rt_render: unknown sampler");
+    if (p->sampler == RT_SAMPLER_EXPLICIT && !p->jitter)
+        return fail(RT_E_INVALID, "rt_render: RT_SAMPLER_EXPLICIT needs a jitter array");
+    if ((int64_t)spp * 256 > (int64_t)1 << 30) return fail(RT_E_LIMIT, "rt_render: samples per pixel too large");
+    const int rows = p->row_end - p->row_begin;
+    const size_t n_pix = size_t(rows) * size_t(W);
+    const size_t n_smp = n_pix * size_t(spp);
+    HIP_TRY(hipSetDevice(c->device));
+    // outputs / jitter of the previous call may still be in flight
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipStreamSynchronize(c->rng_stream));
+
+    int rc;
+    if ((rc = c->jitter.ensure(n_smp * 2))) return rc;
+    if ((rc = c->intensity.ensure(n_pix))) return rc;
+    if ((rc = c->rgb.ensure(n_pix * 3))) return rc;
+    if (p->flags & RT_FLAG_HIT_IDS)
+        if ((rc = c->hit_prim.ensure(n_smp))) return rc;
+    if (p->flags & RT_FLAG_HIT_T)
+        if ((rc = c->hit_t.ensure(n_smp))) return rc;
+    if ((rc = c->counters.ensure(4))) return rc;
+
+    c->stats = rt_stats{};
+    c->stats.rays = n_smp;
+    c->jitter_timed = false;
+
+    // ---- jitter ----
+    if (p->sampler == RT_SAMPLER_EXPLICIT) {
+        HIP_TRY(hipMemcpyAsync(c->jitter.p, p->jitter, n_smp * 2 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    } else {
+        try {
+            const StreamPlan pl = plan_streams(rows, W, spp);
+            const double t0 = now_ms();
+            std::vector<rt::MtState> local_states;
+            rt::MtState end_state;
+            const std::vector<rt::MtState>* states = &local_states;
+            if (c->pre.valid && c->pre.pos == c->pos && c->pre.stride == pl.stride && c->pre.n == pl.n &&
+                c->pre.total_words == pl.total_words) {
+                states = &c->pre.states;
+                end_state = c->pre.end_state;
+            } else {
+                compute_states(c->state, pl, local_states, end_state);
+            }
+            c->stats.host_jump_ms = now_ms() - t0;
+            HIP_TRY(hipEventRecord(c->ev[2], c->rng_stream));
+            rc = launch_jitter(c, *states, pl, c->jitter.p, c->rng_stream);
+            if (rc) return rc;
+            HIP_TRY(hipEventRecord(c->ev[3], c->rng_stream));
+            HIP_TRY(hipEventRecord(c->ev[4], c->rng_stream));
+            HIP_TRY(hipStreamWaitEvent(c->stream, c->ev[4], 0));
+            c->jitter_timed = true;
+            c->state = end_state;
+            c->pos += pl.total_words;
+            if (states == &c->pre.states) {
+                // keep the vector alive until the H2D copy has been staged: it is consumed below
+            }
+        } catch (const std::exception& e) {
+            return fail(RT_E_INVALID, std::string("rt_render: sampler: ") + e.what());
+        }
+    }
+
+    // ---- traversal ----
+    rtk::RenderArgs a;
+    a.sc = dev_scene(c);
+    for (int i = 0; i < 3; ++i) {
+        a.cam[i] = p->camera_center[i];
+        a.p00[i] = p->pixel_00_center[i];
+    }
+    for (int i = 0; i < 6; ++i) a.sp[i] = p->pixel_spacing[i];
+    a.W = W;
+    a.spp = spp;
+    a.row0 = p->row_begin;
+    a.rows = rows;
+    a.tile_log2 = (spp >= 4) ? 3 : 4;  // >= 256 rays per 8x8 tile from 4 spp on
+    const int ts = 1 << a.tile_log2;
+    a.tiles_x = (W + ts - 1) / ts;
+    const int tiles_y = (rows + ts - 1) / ts;
+    const int64_t n_tiles = int64_t(a.tiles_x) * tiles_y;
+    if (n_tiles > 0x7fffffff) return fail(RT_E_LIMIT, "rt_render: too many tiles");
+    a.n_tiles = (int32_t)n_tiles;
+    a.jitter = c->jitter.p;
+    a.intensity = c->intensity.p;
+    a.rgb = c->rgb.p;
+    a.hit_prim = (p->flags & RT_FLAG_HIT_IDS) ? c->hit_prim.p : nullptr;
+    a.hit_t = (p->flags & RT_FLAG_HIT_T) ? c->hit_t.p : nullptr;
+    a.counters = nullptr;
+    a.gstack = nullptr;
+    a.gstack_cap = 0;
+    const int stack = pick_stack(c->stack_need);
+    if (stack == 0) {
+        if ((rc = c->gstack.ensure(size_t(n_tiles) * rtk::NT * size_t(c->stack_need)))) return rc;
+        a.gstack = c->gstack.p;
+        a.gstack_cap = c->stack_need;
+    }
+    const bool count = (p->flags & RT_FLAG_COUNTERS) != 0;
+    if (count) {
+        HIP_TRY(hipMemsetAsync(c->counters.p, 0, 4 * sizeof(unsigned long long), c->stream));
+        a.counters = c->counters.p;
+    }
+    HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+    if (count)
+        launch_render<true>(stack, dim3((unsigned)n_tiles), c->stream, a);
+    else
+        launch_render<false>(stack, dim3((unsigned)n_tiles), c->stream, a);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    c->timing_pending = true;
+    c->out_rows = rows;
+    c->out_w = W;
+    c->out_spp = spp;
+    c->out_flags = p->flags;
+
+    // ---- look-ahead: jump-ahead states for an identical next call, while the GPU works ----
+    if (p->sampler == RT_SAMPLER_MT19937) {
+        try {
+            // the H2D copy of the states used above must have been staged before we overwrite them
+            HIP_TRY(hipEventSynchronize(c->ev[4]));
+            const StreamPlan pl = plan_streams(rows, W, spp);
+            c->pre.valid = false;
+            compute_states(c->state, pl, c->pre.states, c->pre.end_state);
+            c->pre.pos = c->pos;
+            c->pre.stride = pl.stride;
+            c->pre.n = pl.n;
+            c->pre.total_words = pl.total_words;
+            c->pre.valid = true;
+        } catch (const std::exception&) {
+            c->pre.valid = false;
+        }
+    }
+    return RT_OK;
+}
+
+int rt_last_stats(const rt_ctx* cc, rt_stats* out) {
+    if (!cc || !out) return fail(RT_E_INVALID, "rt_last_stats: null argument");
+    rt_ctx* c = const_cast<rt_ctx*>(cc);
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->timing_pending) {
+        HIP_TRY(hipEventSynchronize(c->ev[1]));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+        c->stats.render_kernel_ms = ms;
+        if (c->jitter_timed) {
+            HIP_TRY(hipEventSynchronize(c->ev[3]));
+            HIP_TRY(hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
+            c->stats.jitter_kernel_ms = ms;
+        }
+        if (c->out_flags & RT_FLAG_COUNTERS) {
+            unsigned long long h[4] = {0, 0, 0, 0};
+            HIP_TRY(hipMemcpy(h, c->counters.p, sizeof(h), hipMemcpyDeviceToHost));
+            c->stats.nodes_visited = h[0];
+            c->stats.tris_tested = h[1];
+            c->stats.rays_hit = h[2];
+        }
+        c->timing_pending = false;
+    }
+    *out = c->stats;
+    return RT_OK;
+}
+
+int rt_download(rt_ctx* c, double* intensity, uint8_t* rgb, int32_t* hit_prim, double* hit_t) {
+    if (!c) return fail(RT_E_INVALID, "rt_download: null context");
+    if (c->out_rows == 0) return fail(RT_E_INVALID, "rt_download: nothing rendered yet");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t n_pix = size_t(c->out_rows) * size_t(c->out_w);
+    const size_t n_smp = n_pix * size_t(c->out_spp);
+    if (hit_prim && !(c->out_flags & RT_FLAG_HIT_IDS))
+        return fail(RT_E_INVALID, "rt_download: hit ids were not requested (RT_FLAG_HIT_IDS)");
+    if (hit_t && !(c->out_flags & RT_FLAG_HIT_T))
+        return fail(RT_E_INVALID, "rt_download: hit t was not requested (RT_FLAG_HIT_T)");
+    if (intensity)
+        HIP_TRY(hipMemcpyAsync(intensity, c->intensity.p, n_pix * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (rgb) HIP_TRY(hipMemcpyAsync(rgb, c->rgb.p, n_pix * 3, hipMemcpyDeviceToHost, c->stream));
+    if (hit_prim)
+        HIP_TRY(hipMemcpyAsync(hit_prim, c->hit_prim.p, n_smp * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (hit_t) HIP_TRY(hipMemcpyAsync(hit_t, c->hit_t.p, n_smp * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+int rt_device_outputs(rt_ctx* c, void** intensity, void** rgb, void** hit_prim) {
+    if (!c) return fail(RT_E_INVALID, "rt_device_outputs: null context");
+    if (intensity) *intensity = c->out_rows ? c->intensity.p : nullptr;
+    if (rgb) *rgb = c->out_rows ? c->rgb.p : nullptr;
+    if (hit_prim) *hit_prim = (c->out_rows && (c->out_flags & RT_FLAG_HIT_IDS)) ? c->hit_prim.p : nullptr;
+    return RT_OK;
+}
+
+/* ------------------------------------------------------------------ arbitrary rays */
+int rt_trace_rays(rt_ctx* c, int64_t n, const double* origins, const double* dirs, double* t, double* bary_uvw,
+                  double* color, int32_t* prim) {
+    if (!c || !origins || !dirs || n < 0) return fail(RT_E_INVALID, "rt_trace_rays: bad argument");
+    if (!c->have_scene) return fail(RT_E_NO_SCENE, "rt_trace_rays: no scene uploaded");
+    if (n == 0) return RT_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    int rc;
+    const size_t N = size_t(n);
+    if ((rc = c->tr_o.ensure(N * 3))) return rc;
+    if ((rc = c->tr_d.ensure(N * 3))) return rc;
+    if ((rc = c->tr_t.ensure(N))) return rc;
+    if ((rc = c->tr_b.ensure(N * 3))) return rc;
+    if ((rc = c->tr_c.ensure(N * 3))) return rc;
+    if ((rc = c->tr_p.ensure(N))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->tr_o.p, origins, N * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->tr_d.p, dirs, N * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    rtk::TraceArgs a;
+    a.sc = dev_scene(c);
+    a.n = n;
+    a.origins = c->tr_o.p;
+    a.dirs = c->tr_d.p;
+    a.t = c->tr_t.p;
+    a.bary = c->tr_b.p;
+    a.color = c->tr_c.p;
+    a.prim = c->tr_p.p;
+    a.gstack = nullptr;
+    const int64_t blocks = (n + rtk::NT - 1) / rtk::NT;
+    const int stack = pick_stack(c->stack_need);
+    if (stack == 0) {
+        if ((rc = c->gstack.ensure(size_t(blocks) * rtk::NT * size_t(c->stack_need)))) return rc;
+        a.gstack = c->gstack.p;
+    }
+    launch_trace(stack, dim3((unsigned)blocks), c->stream, a);
+    HIP_TRY(hipGetLastError());
+    if (t) HIP_TRY(hipMemcpyAsync(t, c->tr_t.p, N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (bary_uvw) HIP_TRY(hipMemcpyAsync(bary_uvw, c->tr_b.p, N * 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (color) HIP_TRY(hipMemcpyAsync(color, c->tr_c.p, N * 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (prim) HIP_TRY(hipMemcpyAsync(prim, c->tr_p.p, N * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+/* ------------------------------------------------------------------ PPM + whole-job driver */
+int rt_write_ppm(const char* path, int width, int height, const uint8_t* rgb) {
+    if (!path || !rgb || width < 1 || height < 1) return fail(RT_E_INVALID, "rt_write_ppm: bad argument");
+    FILE* f = std::fopen(path, "wb");
+    if (!f) {
+        std::fprintf(stderr, "Failed to open the output file.\n");  // cpp/rtrender.cpp:72-75
+        return fail(RT_E_IO, std::string("cannot open ") + path);
+    }
+    std::fprintf(f, "P6\n%d %d\n255\n", width, height);
+    std::fwrite(rgb, 1, size_t(width) * size_t(height) * 3, f);
+    std::fclose(f);
+    std::printf("\r Done. \n");  // cpp/rtrender.cpp:81
+    std::fflush(stdout);
+    return RT_OK;
+}
+
+int rt_render_scene(int image_height, int image_width, int number_of_samples, const char* output_directory,
+                    int timestep_count, int n_meshes, const double* const* coords, const double* const* colors,
+                    const int64_t* elem_counts, int n_cameras, const double* camera_centers,
+                    const double* pixel_00_centers, const double* pixel_spacings, int device, int rank, int world) {
+    if (!output_directory || !coords || !colors || !elem_counts || !camera_centers || !pixel_00_centers ||
+        !pixel_spacings)
+        return fail(RT_E_INVALID, "rt_render_scene: null argument");
+    if (timestep_count < 0 || n_cameras < 0 || world < 1 || rank < 0 || rank >= world)
+        return fail(RT_E_INVALID, "rt_render_scene: bad counts");
+    if (device < 0 || device >= 64) return fail(RT_E_INVALID, "rt_render_scene: bad device");
+    rt_ctx* c;
+    {
+        std::lock_guard<std::mutex> lk(g_global_mu);
+        if (!g_global_ctx[device]) g_global_ctx[device] = rt_create(device);
+        c = g_global_ctx[device];
+    }
+    if (!c) return RT_E_NO_DEVICE;  // message set by rt_create
+
+    const uint64_t frame_words = uint64_t(image_height) * uint64_t(image_width) * uint64_t(number_of_samples) * 4u;
+    const uint64_t base = rt_rng_tell(c);
+    std::vector<uint8_t> rgb(size_t(image_height) * size_t(image_width) * 3);
+    int rc = RT_OK;
+    for (int t = 0; t < timestep_count; ++t) {
+        bool mine = false;
+        for (int cam = 0; cam < n_cameras; ++cam)
+            if ((int64_t(t) * n_cameras + cam) % world == rank) mine = true;
+        if (!mine) continue;
+        rt_scene* sc = rt_scene_build(n_meshes, coords, colors, elem_counts, t, 0);
+        if (!sc) return RT_E_INVALID;
+        for (int64_t k = 0; k < sc->s->midpoint_fallbacks; ++k)
+            std::printf("SAH splitting failed. Trying midpoint instead.\n");  // cpp/rtbvh.cpp:128
+        rc = rt_upload_scene(c, sc);
+        rt_scene_free(sc);
+        if (rc) return rc;
+        for (int cam = 0; cam < n_cameras; ++cam) {
+            const int64_t frame = int64_t(t) * n_cameras + cam;
+            if (frame % world != rank) continue;
+            if ((rc = rt_rng_seek(c, base + uint64_t(frame) * frame_words))) return rc;
+            std::printf("Rendering frame %d/%d\n", t + 1, timestep_count);  // cpp/rtmain.cpp:61
+            std::fflush(stdout);
+            rt_render_params p;
+            std::memset(&p, 0, sizeof(p));
+            std::memcpy(p.camera_center, camera_centers + 3 * cam, 3 * sizeof(double));
+            std::memcpy(p.pixel_00_center, pixel_00_centers + 3 * cam, 3 * sizeof(double));
+            std::memcpy(p.pixel_spacing, pixel_spacings + 6 * cam, 6 * sizeof(double));
+            p.image_height = image_height;
+            p.image_width = image_width;
+            p.samples = number_of_samples;
+            p.row_begin = 0;
+            p.row_end = image_height;
+            p.sampler = RT_SAMPLER_MT19937;
+            if ((rc = rt_render(c, &p))) return rc;
+            if ((rc = rt_download(c, nullptr, rgb.data(), nullptr, nullptr))) return rc;
+            // cpp/rtmain.cpp:58-60: rtimage_<timestep>_cam<camera>.ppm, zero-based
+            std::string path = std::string(output_directory) + "/rtimage_" + std::to_string(t) + "_cam" +
+                               std::to_string(cam) + ".ppm";
+            // like the reference, an unopenable file is reported and the job goes on
+            (void)rt_write_ppm(path.c_str(), image_width, image_height, rgb.data());
+        }
+    }
+    // every rank leaves the global stream where the unsharded job would have left it
+    return rt_rng_seek(c, base + uint64_t(timestep_count) * uint64_t(n_cameras) * frame_words);
+}
+
+}  // extern "C"

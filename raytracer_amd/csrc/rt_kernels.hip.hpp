@@ -1,0 +1,491 @@
+// rt_kernels.hip.hpp -- gfx950 device code of the render hot path (included by rt_api.hip).
+//
+// Kernels
+//   mt_jitter_kernel   MT19937 words -> random_double()-0.5 values, one wave per jump-ahead
+//                      stream (reference: cpp/rtmathutils.h:15-19, cpp/rtrender.cpp:53)
+//   render_kernel      ray generation + TLAS/BLAS traversal + Moller-Trumbore + shading +
+//                      in-order sample accumulation + luma/quantise
+//                      (reference: cpp/rtrender.cpp:13-67, cpp/rtrayintersection.cpp:36-228)
+//   trace_kernel       the same traversal for caller-supplied rays (test seam)
+//
+// Numerics contract (parity with the reference's x86-64 -O2 build): IEEE binary64, no FMA
+// contraction (this TU is compiled with -ffp-contract=off), true division and sqrt, every
+// three-term sum as (a+b)+c, min/max with std::min/std::max operand order and NaN behaviour.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rt_bvh.hpp"
+
+namespace rtk {
+
+constexpr int NT = 256;  // threads per workgroup of the traversal kernels (4 waves)
+
+struct DevScene {
+    const rt::DevNode* nodes;
+    const rt::DevNode* tlas;
+    const int32_t* slot_root;
+    const uint32_t* leaf_ext;
+    const double* tris;
+    const double* colors;
+};
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+struct Ray {
+    double ox, oy, oz, dx, dy, dz, ix, iy, iz;
+};
+
+struct Hit {
+    double t, u, v;
+    int32_t prim;
+};
+
+struct Box {
+    double mnx, mny, mnz, mxx, mxy, mxz;
+};
+
+// std::min(a,b) / std::max(a,b) as libstdc++ defines them (operand order matters for NaN)
+__device__ __forceinline__ double std_min(double a, double b) { return (b < a) ? b : a; }
+__device__ __forceinline__ double std_max(double a, double b) { return (a < b) ? b : a; }
+
+__device__ __forceinline__ void load_node(const rt::DevNode* p, Box& b, int32_t& left, int32_t& count,
+                                          int32_t& first, uint32_t& desc) {
+    const d2* q = reinterpret_cast<const d2*>(p);
+    const d2 a = q[0], c = q[1], e = q[2], m = q[3];
+    b.mnx = a.x;
+    b.mny = a.y;
+    b.mnz = c.x;
+    b.mxx = c.y;
+    b.mxy = e.x;
+    b.mxz = e.y;
+    const unsigned long long m0 = (unsigned long long)__double_as_longlong(m.x);
+    const unsigned long long m1 = (unsigned long long)__double_as_longlong(m.y);
+    left = (int32_t)(uint32_t)m0;
+    count = (int32_t)(uint32_t)(m0 >> 32);
+    first = (int32_t)(uint32_t)m1;
+    desc = (uint32_t)(m1 >> 32);
+}
+
+// intersect_AABB, cpp/rtrayintersection.cpp:124-144 (ray.t_max is always +inf).
+// inverse_direction is the same value on every call, so it is computed once per ray.
+__device__ __forceinline__ bool slab(const Ray& r, const Box& b) {
+    const double t0 = (b.mnx - r.ox) * r.ix, t1 = (b.mxx - r.ox) * r.ix;
+    const double t2 = (b.mny - r.oy) * r.iy, t3 = (b.mxy - r.oy) * r.iy;
+    const double t4 = (b.mnz - r.oz) * r.iz, t5 = (b.mxz - r.oz) * r.iz;
+    const double tmin = std_max(std_max(std_min(t0, t1), std_min(t2, t3)), std_min(t4, t5));
+    const double tmax = std_min(std_min(std_max(t0, t1), std_max(t2, t3)), std_max(t4, t5));
+    return tmin <= tmax && tmax > 0.0 && tmin < __builtin_inf();
+}
+
+// One row of intersect_bvh_triangles (cpp/rtrayintersection.cpp:36-122) followed by the
+// closest-hit update.  Scanning triangles one by one with a strict `<` picks the same
+// triangle as the reference's per-leaf minCoeff (first minimal index) + `closest_t < rec.t`.
+__device__ __forceinline__ void tri_test(const Ray& r, const double* __restrict__ tp, int32_t prim, Hit& h) {
+    const double v0x = tp[0], v0y = tp[1], v0z = tp[2];
+    const double e0x = tp[3] - v0x, e0y = tp[4] - v0y, e0z = tp[5] - v0z;
+    const double e2x = tp[6] - v0x, e2y = tp[7] - v0y, e2z = tp[8] - v0z;
+    const double px = r.dy * e2z - r.dz * e2y;
+    const double py = r.dz * e2x - r.dx * e2z;
+    const double pz = r.dx * e2y - r.dy * e2x;
+    const double det = (e0x * px + e0y * py) + e0z * pz;
+    if (det > 1e-6) {  // back faces / parallel: every later value is masked out anyway
+        const double inv = 1.0 / det;
+        const double tvx = r.ox - v0x, tvy = r.oy - v0y, tvz = r.oz - v0z;
+        const double u = ((tvx * px + tvy * py) + tvz * pz) * inv;
+        const double qx = tvy * e0z - tvz * e0y;
+        const double qy = tvz * e0x - tvx * e0z;
+        const double qz = tvx * e0y - tvy * e0x;
+        const double v = ((r.dx * qx + r.dy * qy) + r.dz * qz) * inv;
+        const double t = ((e2x * qx + e2y * qy) + e2z * qz) * inv;
+        const bool ok = (u >= 0.0) && (u <= 1.0) && (v >= 0.0) && ((u + v) <= 1.0) && (t >= 0.0) &&
+                        (t <= __builtin_inf());
+        if (ok && t < h.t) {
+            h.t = t;
+            h.u = u;
+            h.v = v;
+            h.prim = prim;
+        }
+    }
+}
+
+// TLAS -> BLAS traversal in the reference's visit order (left subtree first, TLAS leaves slot
+// by slot, no closest-hit culling: the reference never shrinks t_max).  Each child pair is
+// slab-tested when its parent is visited (one 128-B fetch); only passing children are kept.
+// The set of nodes tested equals the set the reference pops.
+// stk: this lane's stack column, entries `stride` words apart (LDS, or global for deep trees).
+template <bool COUNT>
+__device__ __forceinline__ void trace(const DevScene& sc, const Ray& r, uint32_t* stk, const int stride, Hit& h,
+                                      uint32_t& n_nodes, uint32_t& n_tris) {
+    int sp = 0;
+    uint32_t cur = rt::DESC_TLAS;  // TLAS node 0
+    bool have = true;
+    for (;;) {
+        if (!have) {
+            if (sp == 0) break;
+            --sp;
+            cur = stk[sp * stride];
+        }
+        have = false;
+        if (cur & rt::DESC_LEAF) {
+            uint32_t first = cur & rt::DESC_TRI_MASK;
+            uint32_t cnt = ((cur >> 28) & 7u) + 1u;
+            if (cnt == 8u) {
+                const uint32_t e = first;
+                first = sc.leaf_ext[2 * e];
+                cnt = sc.leaf_ext[2 * e + 1];
+            }
+            if (COUNT) n_tris += cnt;
+            const double* tp = sc.tris + (size_t)first * 9;
+            for (uint32_t k = 0; k < cnt; ++k) tri_test(r, tp + (size_t)k * 9, (int32_t)(first + k), h);
+            continue;
+        }
+        if (cur & (rt::DESC_TLAS | rt::DESC_ROOT)) {
+            Box b;
+            int32_t left, count, first;
+            uint32_t desc;
+            if (cur & rt::DESC_TLAS) {
+                load_node(sc.tlas + (cur & 0x3FFFFFFFu), b, left, count, first, desc);
+                if (COUNT) n_nodes += 1;
+                if (!slab(r, b)) continue;
+                if (left < 0) {
+                    for (int32_t k = count - 1; k >= 0; --k) stk[(sp++) * stride] = rt::DESC_ROOT | (uint32_t)(first + k);
+                } else {
+                    stk[(sp++) * stride] = rt::DESC_TLAS | (uint32_t)(left + 1);
+                    stk[(sp++) * stride] = rt::DESC_TLAS | (uint32_t)left;
+                }
+            } else {
+                const int32_t root = sc.slot_root[cur & 0x1FFFFFFFu];
+                load_node(sc.nodes + root, b, left, count, first, desc);
+                if (COUNT) n_nodes += 1;
+                if (slab(r, b)) {
+                    cur = desc;
+                    have = true;
+                }
+            }
+            continue;
+        }
+        // internal BLAS node: cur = index of its left child; the right child is adjacent
+        Box bl, br;
+        int32_t l0, l1, l2, r0, r1, r2;
+        uint32_t dl, dr;
+        load_node(sc.nodes + cur, bl, l0, l1, l2, dl);
+        load_node(sc.nodes + cur + 1, br, r0, r1, r2, dr);
+        if (COUNT) n_nodes += 2;
+        const bool hl = slab(r, bl), hr = slab(r, br);
+        if (hl) {
+            if (hr) stk[(sp++) * stride] = dr;
+            cur = dl;
+            have = true;
+        } else if (hr) {
+            cur = dr;
+            have = true;
+        }
+    }
+}
+
+__device__ __forceinline__ void make_ray(Ray& r, double ox, double oy, double oz, double dx, double dy, double dz) {
+    r.ox = ox;
+    r.oy = oy;
+    r.oz = oz;
+    r.dx = dx;
+    r.dy = dy;
+    r.dz = dz;
+    r.ix = 1.0 / dx;
+    r.iy = 1.0 / dy;
+    r.iz = 1.0 / dz;
+}
+
+// return_ray_color, cpp/rtrender.cpp:13-33 (set_face_normal is dead work and is not done)
+__device__ __forceinline__ void shade(const DevScene& sc, const Ray& r, const Hit& h, double& c0, double& c1,
+                                      double& c2) {
+    if (h.t != __builtin_inf()) {
+        const double* fc = sc.colors + (size_t)h.prim * 3;
+        const double w = (1.0 - h.u) - h.v;
+        const double f0 = fc[0], f1 = fc[1], f2 = fc[2];
+        c0 = (h.u * f0 + h.v * f0) + w * f0;
+        c1 = (h.u * f1 + h.v * f1) + w * f1;
+        c2 = (h.u * f2 + h.v * f2) + w * f2;
+    } else {
+        const double a = 0.5 * (r.dy + 1.0);
+        const double ia = (1.0 - a) * 1.0;
+        c0 = ia + a * 0.5;
+        c1 = ia + a * 0.7;
+        c2 = ia + a * 1.0;
+    }
+}
+
+struct RenderArgs {
+    DevScene sc;
+    double cam[3], p00[3], sp[6];
+    int32_t W, spp;
+    int32_t row0;      // first image row of this launch (absolute)
+    int32_t rows;      // rows rendered by this launch
+    int32_t tile_log2; // tile side = 1 << tile_log2 (3 or 4)
+    int32_t tiles_x, n_tiles;
+    const double* jitter;  // (rows*W*spp) pairs, sample order (j,i,k), relative to row0
+    double* intensity;     // rows*W
+    uint8_t* rgb;          // rows*W*3
+    int32_t* hit_prim;     // rows*W*spp or null
+    double* hit_t;         // rows*W*spp or null
+    unsigned long long* counters;  // [nodes, tris, hits] or null
+    uint32_t* gstack;      // global stack (deep trees) or null
+    int32_t gstack_cap;
+};
+
+__device__ __forceinline__ uint32_t compact1by1(uint32_t x) {
+    x &= 0x55555555u;
+    x = (x ^ (x >> 1)) & 0x33333333u;
+    x = (x ^ (x >> 2)) & 0x0f0f0f0fu;
+    x = (x ^ (x >> 4)) & 0x00ff00ffu;
+    return x;
+}
+
+// One workgroup renders one square pixel tile.  Rays of the tile are ordered pixel-major in
+// Morton order with the samples of a pixel innermost, so the 64 lanes of a wave hold the
+// samples of one pixel (spp >= 64) or of a compact block of neighbouring pixels.
+// Sample colours go through LDS and are added per pixel in sample order k = 0..spp-1 by one
+// lane per (pixel, channel): the sum is bit-identical to the reference's serial loop
+// (cpp/rtrender.cpp:51-60) for any GPU count or tiling.
+template <int STACK, bool COUNT>
+__global__ __launch_bounds__(NT) void render_kernel(const RenderArgs a) {
+    __shared__ uint32_t s_stk[(STACK > 0 ? STACK : 1) * NT];
+    __shared__ double s_col[3][NT];
+    __shared__ double s_acc[3][NT];
+
+    const int tid = threadIdx.x;
+    // XCD-aware mapping: blocks b and b+8 share an XCD (round-robin dispatch), so give each
+    // XCD a contiguous run of tiles: neighbouring tiles walk the same subtrees -> L2 hits.
+    int tile = blockIdx.x;
+    {
+        const int nb = a.n_tiles, per = nb >> 3, main = per << 3;
+        if ((int)blockIdx.x < main) tile = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+    }
+    const int ts = 1 << a.tile_log2;
+    const int npix_tile = ts * ts;
+    const int tx0 = (tile % a.tiles_x) << a.tile_log2;
+    const int ty0 = (tile / a.tiles_x) << a.tile_log2;
+    const int spp = a.spp;
+    const int n_rays = npix_tile * spp;
+
+    s_acc[0][tid] = 0.0;
+    s_acc[1][tid] = 0.0;
+    s_acc[2][tid] = 0.0;
+
+    uint32_t* stk;
+    int stride;
+    if (STACK > 0) {
+        stk = s_stk + tid;
+        stride = NT;
+    } else {
+        stk = a.gstack + ((size_t)blockIdx.x * NT + tid);
+        stride = (int)(gridDim.x * NT);
+    }
+
+    uint32_t n_nodes = 0, n_tris = 0, n_hits = 0;
+
+    for (int base = 0; base < n_rays; base += NT) {
+        const int rr = base + tid;
+        const int m = rr / spp;
+        const int k = rr - m * spp;
+        const int px = tx0 + (int)compact1by1((uint32_t)m);
+        const int py = ty0 + (int)compact1by1((uint32_t)m >> 1);
+        const bool active = (rr < n_rays) && (px < a.W) && (py < a.rows);
+        double c0 = 0.0, c1 = 0.0, c2 = 0.0;
+        if (active) {
+            const size_t sidx = ((size_t)py * a.W + px) * (size_t)spp + k;
+            const d2 jit = reinterpret_cast<const d2*>(a.jitter)[sidx];
+            // cpp/rtrender.cpp:53-58
+            const double s0 = (double)px + jit.x;
+            const double s1 = (double)(py + a.row0) + jit.y;
+            const double ddx = ((a.p00[0] + s0 * a.sp[0]) + s1 * a.sp[3]) - a.cam[0];
+            const double ddy = ((a.p00[1] + s0 * a.sp[1]) + s1 * a.sp[4]) - a.cam[1];
+            const double ddz = ((a.p00[2] + s0 * a.sp[2]) + s1 * a.sp[5]) - a.cam[2];
+            const double z = (ddx * ddx + ddy * ddy) + ddz * ddz;
+            double dx = ddx, dy = ddy, dz = ddz;
+            if (z > 0.0) {  // Eigen normalized(): v / sqrt(squaredNorm) when squaredNorm > 0
+                const double nz = __builtin_sqrt(z);
+                dx = ddx / nz;
+                dy = ddy / nz;
+                dz = ddz / nz;
+            }
+            Ray r;
+            make_ray(r, a.cam[0], a.cam[1], a.cam[2], dx, dy, dz);
+            Hit h;
+            h.t = __builtin_inf();
+            h.u = 0.0;
+            h.v = 0.0;
+            h.prim = -1;
+            trace<COUNT>(a.sc, r, stk, stride, h, n_nodes, n_tris);
+            shade(a.sc, r, h, c0, c1, c2);
+            if (COUNT) n_hits += (h.prim >= 0);
+            if (a.hit_prim) a.hit_prim[sidx] = h.prim;
+            if (a.hit_t) a.hit_t[sidx] = h.t;
+        }
+        s_col[0][tid] = c0;
+        s_col[1][tid] = c1;
+        s_col[2][tid] = c2;
+        __syncthreads();
+        // in-order accumulation: one lane per (pixel, channel) touched by this batch
+        {
+            const int end = min(base + NT, n_rays);
+            const int m_first = base / spp;
+            const int m_last = (end - 1) / spp;
+            const int work = (m_last - m_first + 1) * 3;
+            for (int q = tid; q < work; q += NT) {
+                const int pm = m_first + q / 3;
+                const int c = q - (q / 3) * 3;
+                const int lo = max(pm * spp, base) - base;
+                const int hi = min((pm + 1) * spp, end) - base;
+                double acc = s_acc[c][pm];
+                for (int s = lo; s < hi; ++s) acc += s_col[c][s];
+                s_acc[c][pm] = acc;
+            }
+        }
+        __syncthreads();
+    }
+
+    if (tid < npix_tile) {
+        const int px = tx0 + (int)compact1by1((uint32_t)tid);
+        const int py = ty0 + (int)compact1by1((uint32_t)tid >> 1);
+        if (px < a.W && py < a.rows) {
+            // cpp/rtrender.cpp:61-65
+            const double gray = (0.2126 * s_acc[0][tid] + 0.7152 * s_acc[1][tid]) + 0.0722 * s_acc[2][tid];
+            const double inten = gray / (double)spp;
+            const int gb = (int)(inten * 255.99);
+            const size_t pidx = (size_t)py * a.W + px;
+            a.intensity[pidx] = inten;
+            const uint8_t g8 = (uint8_t)gb;
+            a.rgb[pidx * 3] = g8;
+            a.rgb[pidx * 3 + 1] = g8;
+            a.rgb[pidx * 3 + 2] = g8;
+        }
+    }
+
+    if (COUNT) {
+        // wave-level reduction, then one atomic per wave and counter
+        unsigned long long v0 = n_nodes, v1 = n_tris, v2 = n_hits;
+        for (int off = 32; off > 0; off >>= 1) {
+            v0 += __shfl_down(v0, off, 64);
+            v1 += __shfl_down(v1, off, 64);
+            v2 += __shfl_down(v2, off, 64);
+        }
+        if ((tid & 63) == 0 && a.counters) {
+            atomicAdd(&a.counters[0], v0);
+            atomicAdd(&a.counters[1], v1);
+            atomicAdd(&a.counters[2], v2);
+        }
+    }
+}
+
+struct TraceArgs {
+    DevScene sc;
+    long long n;
+    const double* origins;
+    const double* dirs;
+    double* t;
+    double* bary;
+    double* color;
+    int32_t* prim;
+    uint32_t* gstack;
+};
+
+template <int STACK>
+__global__ __launch_bounds__(NT) void trace_kernel(const TraceArgs a) {
+    __shared__ uint32_t s_stk[(STACK > 0 ? STACK : 1) * NT];
+    const int tid = threadIdx.x;
+    const long long i = (long long)blockIdx.x * NT + tid;
+    if (i >= a.n) return;
+    uint32_t* stk;
+    int stride;
+    if (STACK > 0) {
+        stk = s_stk + tid;
+        stride = NT;
+    } else {
+        stk = a.gstack + ((size_t)blockIdx.x * NT + tid);
+        stride = (int)(gridDim.x * NT);
+    }
+    Ray r;
+    make_ray(r, a.origins[3 * i], a.origins[3 * i + 1], a.origins[3 * i + 2], a.dirs[3 * i], a.dirs[3 * i + 1],
+             a.dirs[3 * i + 2]);
+    Hit h;
+    h.t = __builtin_inf();
+    h.u = 0.0;
+    h.v = 0.0;
+    h.prim = -1;
+    uint32_t nn = 0, nt = 0;
+    trace<false>(a.sc, r, stk, stride, h, nn, nt);
+    double c0, c1, c2;
+    shade(a.sc, r, h, c0, c1, c2);
+    if (a.t) a.t[i] = h.t;
+    if (a.bary) {
+        // HitRecord::barycentric_coordinates starts as zeros and is only written on a hit
+        const bool hit = h.prim >= 0;
+        a.bary[3 * i] = hit ? h.u : 0.0;
+        a.bary[3 * i + 1] = hit ? h.v : 0.0;
+        a.bary[3 * i + 2] = hit ? (1.0 - h.u) - h.v : 0.0;
+    }
+    if (a.color) {
+        a.color[3 * i] = c0;
+        a.color[3 * i + 1] = c1;
+        a.color[3 * i + 2] = c2;
+    }
+    if (a.prim) a.prim[i] = h.prim;
+}
+
+// ---------------------------------------------------------------------------------------
+// MT19937 jitter.  One wave per stream; the 624-word state lives in LDS and is regenerated
+// in place in ten 64-lane chunks (a chunk only reads words that earlier chunks, or the
+// previous block, produced), then tempered and converted pairwise exactly like libstdc++'s
+// generate_canonical<double,53>: (a + b*2^32) / 2^64, clamped below 1.  Output value is
+// random_double() - 0.5 (cpp/rtrender.cpp:53).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+
+__global__ __launch_bounds__(64) void mt_jitter_kernel(const uint32_t* __restrict__ states, double* __restrict__ out,
+                                                       const unsigned long long doubles_per_stream,
+                                                       const unsigned long long total_doubles) {
+    __shared__ uint32_t x[624];
+    const int lane = threadIdx.x;
+    const unsigned long long stream = blockIdx.x;
+    for (int k = lane; k < 624; k += 64) x[k] = states[stream * 624 + k];
+    unsigned long long pos = stream * doubles_per_stream;
+    unsigned long long end = pos + doubles_per_stream;
+    if (end > total_doubles) end = total_doubles;
+    __syncthreads();
+    for (; pos < end; pos += 312) {
+        for (int c = 0; c < 10; ++c) {
+            const int k = c * 64 + lane;
+            uint32_t nw = 0;
+            if (k < 624) {
+                const uint32_t xa = x[k];
+                const uint32_t xb = x[(k + 1 == 624) ? 0 : k + 1];
+                const uint32_t xm = x[(k + 397 >= 624) ? k + 397 - 624 : k + 397];
+                const uint32_t y = (xa & 0x80000000u) | (xb & 0x7fffffffu);
+                nw = xm ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            }
+            __syncthreads();  // single wave: orders the chunk's reads before its writes
+            if (k < 624) x[k] = nw;
+            __syncthreads();
+        }
+        for (int q = lane; q < 312; q += 64) {
+            if (pos + q < end) {
+                const double wa = (double)mt_temper(x[2 * q]);
+                const double wb = (double)mt_temper(x[2 * q + 1]);
+                const double sum = wa + wb * 4294967296.0;
+                double ret = sum / 18446744073709551616.0;
+                if (ret >= 1.0) ret = 0x1.fffffffffffffp-1;  // nextafter(1.0, 0.0)
+                out[pos + q] = ret - 0.5;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace rtk

@@ -1,0 +1,110 @@
+"""Scene container handed to the renderer.
+
+Host-side mirror of the reference's ``rtscene`` module (rtscene.py:8-126): the same field and method
+names and the same clip / fill semantics, so scripts written against the reference keep working.
+Meshes are lists of per-mesh arrays: coordinates (T, E, 3, 3) and face colours (T, E, 3).
+"""
+from dataclasses import dataclass, field
+from enum import Enum
+
+import numpy as np
+
+
+class RenderType(Enum):
+    STATIC = 0
+    DYNAMIC = 1
+
+
+@dataclass
+class RTMesh:
+    """Minimal stand-in for the reference's rtsimdataloader_new.RTMesh (only what Scene.add_rtmesh reads)."""
+    node_coords: np.ndarray = None
+    connectivity: np.ndarray = None
+    node_coords_expanded_over_time: np.ndarray = None
+    face_colors_over_time: np.ndarray = None
+    surface_type: str = None
+    timestep_count: int = 1
+
+
+@dataclass
+class Scene:
+    scene_connectivity: list = field(default_factory=list)
+    scene_coords: list = field(default_factory=list)
+    coords_expanded: list = field(default_factory=list)
+    deform_vals: list = field(default_factory=list)
+    face_colors: list = field(default_factory=list)
+    camera_center: list = field(default_factory=list)
+    pixel_00_center: list = field(default_factory=list)
+    matrix_pixel_spacing: list = field(default_factory=list)
+    timestep_count: int = 1
+    mesh_count: int = 0
+
+    def add_camera(self, camera_center, pixel_00_center, matrix_pixel_spacing):
+        self.camera_center.append(camera_center)
+        self.pixel_00_center.append(pixel_00_center)
+        self.matrix_pixel_spacing.append(matrix_pixel_spacing)
+
+    def add_mesh(self, node_coords_expanded, coords, connectivity, face_colors, timestep_count):
+        """rtscene.py:34-42."""
+        self.coords_expanded.append(node_coords_expanded)
+        self.scene_coords.append(coords)
+        self.scene_connectivity.append(connectivity)
+        self.face_colors.append(face_colors)
+        self.mesh_count += 1
+        self.timestep_count = max(self.timestep_count, timestep_count)
+
+    def add_rtmesh(self, rtmesh):
+        """rtscene.py:44-55 (note: like the reference it does not bump mesh_count)."""
+        self.scene_coords.append(rtmesh.node_coords)
+        self.scene_connectivity.append(rtmesh.connectivity)
+        if rtmesh.surface_type is None:
+            print("Please set surface type for mesh before adding it to the scene.")
+            return
+        self.coords_expanded.append(rtmesh.node_coords_expanded_over_time)
+        if str(rtmesh.surface_type) == "field_color":
+            self.face_colors.append(rtmesh.face_colors_over_time)
+        self.timestep_count = max(self.timestep_count, rtmesh.timestep_count)
+
+    def fill_empty_timesteps(self):
+        """Pad meshes that have fewer timesteps than the scene: repeat the last known coordinates and
+        colour the padded steps mid-grey 0.5 (rtscene.py:57-83)."""
+        for m in range(self.mesh_count):
+            have, elements = self.coords_expanded[m].shape[:2]
+            missing = self.timestep_count - have
+            if missing <= 0:
+                continue
+            reps = [1] * (have - 1) + [missing + 1]
+            self.coords_expanded[m] = np.ascontiguousarray(np.repeat(self.coords_expanded[m], reps, axis=0))
+            pad = np.ones((missing, elements, 3)) * 0.5
+            self.face_colors[m] = np.ascontiguousarray(np.concatenate((self.face_colors[m], pad), axis=0))
+
+    def clip_scene(self, frames_to_render, render_type):
+        """DYNAMIC: keep the first ``frames_to_render`` timesteps.  STATIC: keep ``[:frames_to_render]``
+        and set timestep_count to 1, so the renderer draws timestep 0 of the slice (rtscene.py:85-110)."""
+        if render_type == RenderType.DYNAMIC:
+            if frames_to_render == self.timestep_count:
+                return
+            self.timestep_count = frames_to_render
+            for m in range(self.mesh_count):
+                self.coords_expanded[m] = self.coords_expanded[m][:frames_to_render]
+                self.face_colors[m] = self.face_colors[m][:frames_to_render]
+        elif render_type == RenderType.STATIC:
+            if any(self.coords_expanded[m].shape[0] < frames_to_render for m in range(self.mesh_count)):
+                self.timestep_count = frames_to_render
+                self.fill_empty_timesteps()
+            for m in range(self.mesh_count):
+                self.coords_expanded[m] = self.coords_expanded[m][:frames_to_render]
+                self.face_colors[m] = self.face_colors[m][:frames_to_render]
+            self.timestep_count = 1
+
+
+def find_max_displacements(scene, render_type):
+    """Largest nodal displacement per mesh and timestep (rtscene.py:113-126; unused by the renderer)."""
+    out = np.zeros((scene.mesh_count, scene.timestep_count))
+    if render_type == RenderType.STATIC:
+        return out
+    for m in range(scene.mesh_count):
+        for t in range(1, scene.timestep_count - 1):
+            step = scene.coords_expanded[m][t + 1] - scene.coords_expanded[m][t]
+            out[m, t] = np.max(np.linalg.norm(step, axis=2), axis=(0, 1))
+    return out

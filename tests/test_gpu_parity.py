@@ -1,0 +1,289 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the same seeded
+inputs.  Bars (BASELINE.json north_star): per-sample hit triangle bit-exact, pixel intensity within 1e-6
+abs -- we additionally assert bit-equality of intensities, t, barycentrics and the P6 payload, which the
+fp64 no-FMA kernel is designed to deliver.  Run with -m gpu on an MI355X."""
+import os
+
+import numpy as np
+import pytest
+
+import orc
+import raytracer_amd as ra
+from raytracer_amd import meshgen
+
+pytestmark = pytest.mark.gpu
+
+INTENSITY_TOL = 1e-6  # north_star tolerance; tests also check exact equality
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float64).view(np.uint64)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = ra.Context(0)
+    yield c
+    c.close()
+
+
+def check_image(ctx, coords, colors, cam, H, W, spp, timestep=0, jitter=None, seed_pos=0):
+    host = ra.HostScene(coords, colors, timestep)
+    ctx.upload(host)
+    oscene = orc.Scene(coords, colors, timestep)
+    cc, p00, sp = cam
+    if jitter is None:
+        ctx.rng_seed(5489)
+        ctx.rng_seek(seed_pos)
+        rng = orc.Rng(5489)
+        rng.discard(seed_pos)
+        want = oscene.render(cc, p00, sp, H, W, spp, rng=rng)
+    else:
+        want = oscene.render(cc, p00, sp, H, W, spp, jitter=jitter)
+    ctx.render(cc, p00, sp, H, W, spp, jitter=jitter, hit_ids=True, hit_t=True)
+    got = ctx.download()
+    if jitter is None:
+        assert ctx.rng_tell() == seed_pos + H * W * spp * 4
+    mesh, elem = host.map_prims(got["hit_prim"])
+    assert np.array_equal(mesh, want["hit_mesh"]), "hit mesh ids differ"
+    assert np.array_equal(elem, want["hit_elem"]), "hit element ids differ"
+    assert np.array_equal(bits(got["hit_t"]), bits(want["hit_t"]))
+    assert np.max(np.abs(got["intensity"] - want["intensity"])) <= INTENSITY_TOL
+    assert np.array_equal(bits(got["intensity"]), bits(want["intensity"]))
+    assert np.array_equal(got["rgb"], want["rgb"])
+    return got, want, host
+
+
+def test_jitter_stream_matches_reference_rng(ctx):
+    for n, streams in [(10, 1), (624, 1), (5000, 3), (100000, 7), (312 * 8, 4)]:
+        ctx.rng_seed(5489)
+        got = ctx.rng_jitter(n, streams)
+        want = orc.Rng(5489).doubles(n) - 0.5
+        assert np.array_equal(bits(got), bits(want)), (n, streams)
+        assert ctx.rng_tell() == 2 * n
+    # continuation + seek
+    ctx.rng_seed(5489)
+    a = ctx.rng_jitter(1000, 2)
+    b = ctx.rng_jitter(1000, 5)
+    want = orc.Rng(5489).doubles(2000) - 0.5
+    assert np.array_equal(bits(np.concatenate([a, b])), bits(want))
+    ctx.rng_seek(2 * 777)
+    c = ctx.rng_jitter(100, 2)
+    assert np.array_equal(bits(c), bits(want[777:877]))
+
+
+def test_trace_rays_random_soup(ctx):
+    c, k = meshgen.random_soup(3000, seed=7)
+    host = ra.HostScene([c], [k])
+    ctx.upload(host)
+    o = orc.Scene([c], [k])
+    rng = np.random.default_rng(3)
+    n = 20000
+    org = np.zeros((n, 3)) + rng.uniform(-0.5, 0.5, (n, 3))
+    d = np.stack([rng.uniform(-1, 1, n), rng.uniform(-1, 1, n), -np.ones(n)], -1)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    got = ctx.trace(org, d)
+    want = o.trace(org, d)
+    mesh, elem = host.map_prims(got["prim"])
+    assert (want["elem"] >= 0).sum() > 2000
+    assert np.array_equal(elem, want["elem"]) and np.array_equal(mesh, want["mesh"])
+    assert np.array_equal(bits(got["t"]), bits(want["t"]))
+    assert np.array_equal(bits(got["bary"]), bits(want["bary"]))
+    assert np.array_equal(bits(got["color"]), bits(want["color"]))
+
+
+def test_trace_axis_aligned_rays_nan_slab_order(ctx):
+    """Direction components exactly +-0 and origins on box planes: 0*inf = NaN inside the slab test; the
+    kernel must follow std::min/std::max operand order (rtrayintersection.cpp:136-138)."""
+    tris = []
+    for ix in range(-3, 3):
+        for iy in range(-3, 3):
+            z = -2.0 - ((ix + iy) % 3)
+            tris.append([[ix, iy, z], [ix + 1, iy, z], [ix, iy + 1, z]])
+            tris.append([[ix + 1, iy, z], [ix + 1, iy + 1, z], [ix, iy + 1, z]])
+    c = np.array(tris, float)[None]
+    k = np.linspace(0.1, 0.9, c.shape[1])[None, :, None].repeat(3, 2)
+    host = ra.HostScene([c], [k])
+    ctx.upload(host)
+    o = orc.Scene([c], [k])
+    org, d = [], []
+    for x in np.arange(-3, 3.01, 0.5):
+        for y in np.arange(-3, 3.01, 0.5):
+            for dz in (-1.0,):
+                for dx, dy in ((0.0, 0.0), (-0.0, 0.0), (0.0, -0.0), (1.0, 0.0), (0.0, 1.0)):
+                    org.append([x, y, 0.0])
+                    v = np.array([dx, dy, dz if (dx == 0 and dy == 0) else 0.0])
+                    d.append(v)
+    org, d = np.array(org), np.array(d)
+    got = ctx.trace(org, d)
+    want = o.trace(org, d)
+    mesh, elem = host.map_prims(got["prim"])
+    assert np.array_equal(elem, want["elem"])
+    assert np.array_equal(bits(got["t"]), bits(want["t"]))
+    assert np.array_equal(bits(got["color"]), bits(want["color"]))
+    assert (want["elem"] >= 0).sum() > 50
+
+
+@pytest.mark.parametrize("spp", [1, 3, 4, 50, 64])
+def test_render_plate_matches_oracle(ctx, spp):
+    c, k = meshgen.plate(48)
+    cam = meshgen.camera_arrays(40, 24)
+    got, want, _ = check_image(ctx, [c], [k], cam, 24, 40, spp)
+    assert (want["hit_elem"] >= 0).mean() > 0.5
+
+
+def test_render_odd_sizes_and_stream_position(ctx):
+    c, k = meshgen.plate(20)
+    cam = meshgen.camera_arrays(37, 19, center=(0.3, -0.2, 0.5), target=(0.1, 0.0, -1.0), fov=70)
+    check_image(ctx, [c], [k], cam, 19, 37, 5, seed_pos=4 * 12345)
+    cam = meshgen.camera_arrays(1, 1)
+    check_image(ctx, [c], [k], cam, 1, 1, 1)
+    cam = meshgen.camera_arrays(3, 70)
+    check_image(ctx, [c], [k], cam, 70, 3, 2)
+
+
+@pytest.mark.parametrize("n_meshes", [2, 3, 5, 8])
+def test_render_multi_mesh_including_slot_quirk(ctx, n_meshes):
+    rng = np.random.default_rng(50 + n_meshes)
+    coords, colors = [], []
+    for m in range(n_meshes):
+        c, k = meshgen.uv_sphere(10, 14, radius=0.8, center=tuple(rng.uniform(-3, 3, 2)) + (-6.0 + rng.uniform(-1, 1),))
+        coords.append(c)
+        colors.append(k * (0.2 + 0.1 * m))
+    cam = meshgen.camera_arrays(48, 32)
+    got, want, _ = check_image(ctx, coords, colors, cam, 32, 48, 4)
+    assert (want["hit_mesh"] >= 0).any()
+
+
+def test_unjittered_rays_through_shared_vertices_ties(ctx):
+    """Zero jitter sends rays exactly through grid vertices/edges of a flat plate: equal-t candidates in
+    neighbouring triangles; first-found (reference traversal order) must win."""
+    c, k = meshgen.plate(8, side=8.0, z0=-4.0, amp=0.0)
+    H = W = 9
+    cam = (np.zeros(3), np.array([-4.0, 4.0, -4.0]), np.array([[1.0, 0, 0], [0, -1.0, 0]]))
+    jit = np.zeros((H * W * 1, 2))
+    got, want, _ = check_image(ctx, [c], [k], cam, H, W, 1, jitter=jit)
+    assert (want["hit_elem"] >= 0).sum() >= 60
+
+
+def test_duplicate_meshes_and_big_leaves(ctx):
+    # nine coincident triangles (one oversized leaf -> leaf_ext path) twice (two coincident meshes)
+    base = np.array([[-2.0, -2, -3], [2, -2, -3], [0, 2, -3]])
+    c = np.repeat(base[None], 9, axis=0)[None]
+    k = (np.arange(9)[None, :, None] / 10.0 + 0.05).repeat(3, 2)
+    cam = meshgen.camera_arrays(16, 12)
+    got, want, host = check_image(ctx, [c, c.copy()], [k, k * 0.5], cam, 12, 16, 2)
+    assert host.info.max_leaf_tris == 9
+    hit = want["hit_elem"][want["hit_elem"] >= 0]
+    assert hit.size and (hit == hit[0]).all()  # the first-found triangle wins every tie
+
+
+def test_deep_tree_uses_global_stack(ctx):
+    # geometric spacing makes the binned split peel off few elements per level: a very deep, left-leaning tree
+    tris = []
+    n_t = 300
+    for i in range(n_t):
+        x = 3.0 ** i * 1e-6
+        tris.append([[x, -1.0, -3.0], [x * 1.5, -1.0, -3.0], [x, 1.0, -3.0]])
+    c = np.array(tris)[None]
+    k = np.linspace(0.2, 0.8, n_t)[None, :, None].repeat(3, 2)
+    host = ra.HostScene([c], [k])
+    assert host.info.stack_need > 48, host.info.stack_need
+    ctx.upload(host)
+    o = orc.Scene([c], [k])
+    rng = np.random.default_rng(0)
+    n = 4000
+    xi = 3.0 ** rng.integers(0, n_t, n) * 1e-6
+    org = np.stack([xi * rng.uniform(0.9, 1.6, n), rng.uniform(-0.9, 0.7, n), np.zeros(n)], -1)
+    d = np.tile([0.0, 0.0, -1.0], (n, 1)) + rng.uniform(-1e-4, 1e-4, (n, 3))
+    got = ctx.trace(org, d)
+    want = o.trace(org, d)
+    _, elem = host.map_prims(got["prim"])
+    assert np.array_equal(elem, want["elem"])
+    assert np.array_equal(bits(got["t"]), bits(want["t"]))
+    assert (want["elem"] >= 0).sum() > 1000
+    cam = meshgen.camera_arrays(8, 8)
+    check_image(ctx, [c], [k], cam, 8, 8, 2)
+
+
+def test_row_bands_equal_full_image(ctx):
+    c, k = meshgen.plate(32)
+    H, W, spp = 40, 24, 3
+    cam = meshgen.camera_arrays(W, H)
+    host = ra.HostScene([c], [k])
+    ctx.upload(host)
+    ctx.rng_seed(5489)
+    ctx.render(*cam, H, W, spp, hit_ids=True)
+    full = ctx.download()
+    parts = []
+    for a, b in [(0, 7), (7, 8), (8, 33), (33, 40)]:
+        ctx.rng_seek(a * W * spp * 4)
+        ctx.render(*cam, H, W, spp, rows=(a, b), hit_ids=True)
+        parts.append(ctx.download())
+    assert np.array_equal(np.concatenate([p["rgb"] for p in parts]), full["rgb"])
+    assert np.array_equal(bits(np.concatenate([p["intensity"] for p in parts])), bits(full["intensity"]))
+    assert np.array_equal(np.concatenate([p["hit_prim"] for p in parts]), full["hit_prim"])
+
+
+def test_counters_match_oracle_visit_counts(ctx):
+    c, k = meshgen.plate(64)
+    H, W, spp = 32, 32, 2
+    cam = meshgen.camera_arrays(W, H)
+    host = ra.HostScene([c], [k])
+    ctx.upload(host)
+    ctx.rng_seed(5489)
+    ctx.render(*cam, H, W, spp, counters=True)
+    st = ctx.stats()
+    want = orc.Scene([c], [k]).render(*cam, H, W, spp, rng=orc.Rng())
+    assert st["rays"] == H * W * spp
+    assert st["nodes_visited"] == want["nodes"]
+    assert st["tris_tested"] == want["tris"]
+    assert st["rays_hit"] == want["hits"]
+    assert st["render_kernel_ms"] > 0
+
+
+def test_render_scene_driver_files_and_sharding(ctx, tmp_path):
+    """rt_render_scene == the reference's render_scene loop (rtmain.cpp:49-64): timestep outer, camera inner,
+    one never-reseeded RNG stream across frames, files rtimage_<t>_cam<c>.ppm."""
+    c, k = meshgen.plate(16, T=3, sway=0.2)
+    c2, k2 = meshgen.uv_sphere(8, 10, radius=1.0, center=(0.5, 0.5, -3.0), T=3)
+    H, W, spp = 18, 30, 2
+    cams = [meshgen.camera_arrays(W, H), meshgen.camera_arrays(W, H, center=(0.5, 0.2, 0.3), target=(0, 0, -2), fov=60)]
+    sc = ra.Scene()
+    sc.add_mesh(c, None, None, k, 3)
+    sc.add_mesh(c2, None, None, k2, 3)
+    for cc, p00, sp in cams:
+        sc.add_camera(cc, p00, sp)
+    out = tmp_path / "all"
+    out.mkdir()
+    from raytracer_amd import _lib as L
+    # the driver uses a process-global context per device; start its stream at a known position
+    # by rendering relative to wherever it is: compare against an oracle stream discarded to that offset.
+    import ctypes as C
+    # render everything on "rank 0 of 1"
+    base_probe = tmp_path / "probe"
+    base_probe.mkdir()
+    ra.render_scene(H, W, sc, spp, out)
+    names = sorted(os.listdir(out))
+    assert names == [f"rtimage_{t}_cam{cam}.ppm" for t in range(3) for cam in range(2)]
+    # oracle: one continuous stream across (t, cam).  The global stream started at some multiple of the
+    # frame size only if this is the first driver call in the process; find the base from the first frame.
+    frame_words = H * W * spp * 4
+    hdr = f"P6\n{W} {H}\n255\n".encode()
+    found_base = None
+    for base_frames in range(0, 64):
+        rng = orc.Rng()
+        rng.discard(base_frames * frame_words)
+        want = orc.Scene([c, c2], [k, k2], 0).render(*cams[0], H, W, spp, rng=rng, want_hits=False)
+        if (out / "rtimage_0_cam0.ppm").read_bytes() == hdr + want["rgb"].tobytes():
+            found_base = base_frames
+            break
+    assert found_base is not None, "first frame does not match the oracle at any frame-aligned stream offset"
+    rng = orc.Rng()
+    rng.discard(found_base * frame_words)
+    for t in range(3):
+        osc = orc.Scene([c, c2], [k, k2], t)
+        for ci, cam in enumerate(cams):
+            want = osc.render(*cam, H, W, spp, rng=rng, want_hits=False)
+            data = (out / f"rtimage_{t}_cam{ci}.ppm").read_bytes()
+            assert data == hdr + want["rgb"].tobytes(), (t, ci)

@@ -1,0 +1,63 @@
+"""Host side of the sampler: GF(2) jump-ahead of MT19937 (raytracer_amd/csrc/rt_mt19937.cpp) against
+sequential generation by the oracle's generator (which is pinned to the reference's random_double()).
+CPU only."""
+import numpy as np
+import pytest
+
+import orc
+import raytracer_amd as ra
+
+UPPER = np.uint32(0x80000000)
+
+
+def oracle_words_from_state(state, n):
+    """Continue an MT19937 from a raw 624-word window (reference algorithm, numpy, vectorised blocks)."""
+    x = state.copy()
+    out = np.empty(n, np.uint32)
+    got = 0
+    while got < n:
+        for k in range(624):
+            y = (x[k] & UPPER) | (x[(k + 1) % 624] & np.uint32(0x7FFFFFFF))
+            x[k] = x[(k + 397) % 624] ^ (y >> np.uint32(1)) ^ (np.uint32(0x9908B0DF) if (y & np.uint32(1)) else np.uint32(0))
+        y = x.copy()
+        y ^= y >> np.uint32(11)
+        y ^= (y << np.uint32(7)) & np.uint32(0x9D2C5680)
+        y ^= (y << np.uint32(15)) & np.uint32(0xEFC60000)
+        y ^= y >> np.uint32(18)
+        m = min(624, n - got)
+        out[got:got + m] = y[:m]
+        got += m
+    return out
+
+
+@pytest.mark.parametrize("pos", [0, 1, 2, 623, 624, 625, 1000, 19937, 360000, 2**20 + 12345])
+def test_state_at_matches_sequential(pos):
+    st = ra.mt19937_state_at(pos)
+    r = orc.Rng(5489)
+    r.discard(pos)
+    want = r.u32(700)
+    got = oracle_words_from_state(st, 700)
+    assert np.array_equal(got, want)
+
+
+def test_far_jump_is_consistent():
+    # 2^40 + 7 reached in one jump == reached in two jumps through the stream-state helper
+    a = ra.mt19937_state_at(2**40 + 7)
+    b = ra.mt19937_stream_states(7, 2**39, 3)[2]
+    assert np.array_equal(oracle_words_from_state(a, 64), oracle_words_from_state(b, 64))
+
+
+def test_stream_states_tree_doubling():
+    base, stride, n = 4000, 6 * 400 * 4, 7  # 7 streams: not a power of two
+    states = ra.mt19937_stream_states(base, stride, n)
+    for r in range(n):
+        g = orc.Rng(5489)
+        g.discard(base + r * stride)
+        assert np.array_equal(oracle_words_from_state(states[r], 64), g.u32(64)), r
+
+
+def test_other_seed():
+    st = ra.mt19937_state_at(5000, seed=12345)
+    r = orc.Rng(12345)
+    r.discard(5000)
+    assert np.array_equal(oracle_words_from_state(st, 100), r.u32(100))
