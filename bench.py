@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""bench.py -- Mrays/s of the render hot path on MI355X (contract: see the round prompt / DESIGN.md).
+
+A "step" is one full frame of the workload: MT19937 jitter generation (host jump-ahead + jitter
+kernel), ray generation, TLAS/BLAS traversal, Moller-Trumbore, shading, in-order sample accumulation,
+quantisation and per-sample hit-id output, with the flattened tree already resident in HBM (the host
+BVH build and the upload happen before the timed region and are reported separately).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4|plate1m|sphere]
+
+N > 1 is launched by torch.distributed.run, one rank per GPU; frames are sharded over ranks
+(frame f = step*N + rank, each at its own position of the reference's global RNG stream), with no
+data-path collective: only the barrier and the MAX-over-ranks of the elapsed time.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def workload(name):
+    """-> (label, coords list, colors list, (cam, p00, spacing), H, W, spp)"""
+    from raytracer_amd import meshgen
+    if name == "c4":
+        # BASELINE.json configs[3]: 5M-triangle deformed plate, 4096x4096, 64 spp, several BLAS under one TLAS
+        n = 791  # 4 plates x 2*791^2 = 5,005,448 triangles
+        coords, colors = meshgen.plate_grid(n, grid=(2, 2), side=10.0)
+        H = W = 4096
+        spp = 64
+        label = "configs[3]: synthetic 5M-triangle deformed plate (4 BLAS / 1 TLAS), 4096x4096, 64 spp"
+    elif name == "plate1m":
+        c, k = meshgen.plate(724)  # 1,048,352 triangles, north_star's >=1M-triangle / 50 spp target
+        coords, colors = [c], [k]
+        H = W = 2048
+        spp = 50
+        label = "1,048,352-triangle deformed plate (1 BLAS), 2048x2048, 50 spp"
+    elif name == "sphere":
+        c, k = meshgen.uv_sphere(50, 50, radius=1.0, center=(0.0, 0.0, -2.5))
+        coords, colors = [c], [k]
+        H, W, spp = 225, 400, 50
+        label = "configs[1]-shaped: 4,900-triangle sphere, 400x225, 50 spp"
+    else:
+        raise SystemExit(f"unknown workload {name}")
+    cam = meshgen.camera_arrays(W, H)
+    return label, coords, colors, cam, H, W, spp
+
+
+def b_ray(nodes, tris, hits, rays, spp):
+    """Algorithmic bytes per ray, SURVEY.md section 8(d): 64*N_node + 72*N_tri + 24*[hit] + 16 + 4 + 8/spp."""
+    return 64.0 * nodes / rays + 72.0 * tris / rays + 24.0 * hits / rays + 16.0 + 4.0 + 8.0 / spp
+
+
+def cpu_baseline(coords, colors, cam, H, W, spp, ctx_check, host, budget_rays):
+    """The oracle (plain-C restatement, 1 thread) timed on a bounded, stratified sample of the same
+    frame: whole rows spread over the image, each started at its exact position of the RNG stream.
+    The same rows are compared with the GPU frame (hit ids bit-exact, intensity <= 1e-6)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc  # the checker; never on the product path
+    import raytracer_amd as ra
+
+    t0 = time.time()
+    oscene = orc.Scene(coords, colors, 0)
+    build_s = time.time() - t0
+    n_rows = max(1, min(H, int(budget_rays // (W * spp))))
+    rows = sorted(set(int((i + 0.5) * H / n_rows) for i in range(n_rows)))
+    rays = 0
+    secs = 0.0
+    nodes = tris = hits = 0
+    mismatches = 0
+    max_abs = 0.0
+    for r in rows:
+        rng = orc.Rng()
+        rng.set_state(ra.mt19937_state_at(r * W * spp * 4))
+        t0 = time.time()
+        w = oscene.render(*cam, H, W, spp, rng=rng, row0=r, row1=r + 1)
+        secs += time.time() - t0
+        rays += W * spp
+        nodes += w["nodes"]
+        tris += w["tris"]
+        hits += w["hits"]
+        if ctx_check is not None:
+            g = ctx_check
+            sl = slice(r * W * spp, (r + 1) * W * spp)
+            mesh, elem = host.map_prims(g["hit_prim"][sl])
+            mismatches += int((mesh != w["hit_mesh"]).sum() + (elem != w["hit_elem"]).sum())
+            max_abs = max(max_abs, float(np.max(np.abs(g["intensity"][r] - w["intensity"][0]))))
+    return dict(value=rays / secs / 1e6, unit="Mrays/s", cores=1, kind="port",
+                sample=f"{len(rows)} full rows spread over the frame = {rays} rays, {secs:.1f} s "
+                       f"(oracle BVH build {build_s:.1f} s not included)",
+                nodes_per_ray=nodes / rays, tris_per_ray=tris / rays, hit_rate=hits / rays,
+                b_ray=b_ray(nodes, tris, hits, rays, spp),
+                gpu_vs_oracle=dict(hit_id_mismatches=mismatches, max_abs_intensity_diff=max_abs,
+                                   rows_checked=len(rows)) if ctx_check is not None else None)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default=os.environ.get("RT_BENCH_WORKLOAD", "c4"))
+    ap.add_argument("--cpu-rays", type=float, default=12e6, help="rays in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-hit-ids", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import raytracer_amd as ra
+
+    label, coords, colors, cam, H, W, spp = workload(args.workload)
+    t0 = time.time()
+    host = ra.HostScene(coords, colors, 0)
+    build_s = time.time() - t0
+    ctx = ra.Context(local_rank)
+    t0 = time.time()
+    ctx.upload(host)
+    upload_s = time.time() - t0
+    rays_per_frame = H * W * spp
+    frame_words = rays_per_frame * 4
+    want_ids = not args.no_hit_ids
+
+    def frame(step_idx, **kw):
+        # frame f of the sequence sits at position f*frame_words of the reference's global stream
+        f = step_idx * world + rank
+        ctx.rng_seek(f * frame_words)
+        ctx.render(*cam, H, W, spp, hit_ids=want_ids, **kw)
+
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for s in range(args.warmup):
+        frame(s)
+    barrier()
+    kernel_ms = []
+    jitter_ms = []
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        frame(args.warmup + s)
+        # stats of the PREVIOUS launch would stall the pipeline; collect after the loop for the last one,
+        # and per step only when the render has to be waited for anyway (rt_render syncs at entry)
+        st = None
+        if s == args.steps - 1:
+            ctx.sync()
+            st = ctx.stats()
+        if st:
+            kernel_ms.append(st["render_kernel_ms"])
+            jitter_ms.append(st["jitter_kernel_ms"])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # untimed extras on rank 0: per-launch kernel time over several launches, visit counters, CPU baseline
+    out = None
+    if rank == 0:
+        ks = []
+        for s in range(max(2, min(args.steps, 3))):
+            frame(0)
+            ctx.sync()
+            ks.append(ctx.stats())
+        kms = float(np.mean([k["render_kernel_ms"] for k in ks]))
+        jms = float(np.mean([k["jitter_kernel_ms"] for k in ks]))
+        hjm = float(np.mean([k["host_jump_ms"] for k in ks]))
+        frame(0, counters=True)
+        ctx.sync()
+        cs = ctx.stats()
+        bray = b_ray(cs["nodes_visited"], cs["tris_tested"], cs["rays_hit"], cs["rays"], spp)
+        achieved = rays_per_frame * bray / (kms * 1e-3) / 1e9
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", f"pmc_{args.workload}.json")
+        if os.path.exists(pmc_path):
+            try:
+                traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        cpu = None
+        if args.cpu_rays > 0:
+            frame(0)
+            got = ctx.download(rgb=False, hit_ids=want_ids)
+            if want_ids:
+                cpu = cpu_baseline(coords, colors, cam, H, W, spp, got, host, args.cpu_rays)
+            else:
+                cpu = cpu_baseline(coords, colors, cam, H, W, spp, None, host, args.cpu_rays)
+        total_rays = rays_per_frame * args.steps * world
+        value = total_rays / elapsed / 1e6
+        out = {
+            "metric": "Mrays/s (primary+AA samples)",
+            "value": value,
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": label, "image": [H, W], "spp": spp, "triangles": int(host.info.n_tris),
+                       "blas": int(host.info.n_meshes), "bvh_nodes": int(host.info.n_blas_nodes),
+                       "sampler": "MT19937 reference stream (GPU jitter kernel, host GF(2) jump-ahead)",
+                       "hit_ids_written": want_ids, "frames_per_step_per_gpu": 1,
+                       "parallelism": f"frame-sharded x{world}, no collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "rtk::render_kernel", "kernel_ms": kms, "bytes_per_ray": bray,
+                         "rays_per_launch": rays_per_frame, "nodes_per_ray": cs["nodes_visited"] / cs["rays"],
+                         "tris_per_ray": cs["tris_tested"] / cs["rays"], "hit_rate": cs["rays_hit"] / cs["rays"],
+                         "kernel_only_mrays_s": rays_per_frame / (kms * 1e-3) / 1e6},
+            "cpu_baseline": cpu,
+            "aux": {"jitter_kernel_ms": jms, "host_jump_ms_per_frame": hjm, "host_bvh_build_s": build_s,
+                    "upload_s": upload_s, "stack_need": int(host.info.stack_need)},
+        }
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if out is not None:
+        print(json.dumps(out))
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

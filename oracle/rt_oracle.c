@@ -103,6 +103,12 @@ ORC_API void orc_rng_fill_u32(orc_rng *r, uint32_t *out, uint64_t n) {
 ORC_API void orc_rng_fill_double(orc_rng *r, double *out, uint64_t n) {
     for (uint64_t i = 0; i < n; ++i) out[i] = rng_double(r);
 }
+/* raw state injection: lets the full-size checks start the oracle's generator at a far stream
+ * position (the state comes from a jump that tests/test_mt_jump.py validates against discard()) */
+ORC_API void orc_rng_set_state(orc_rng *r, const uint32_t *mt624) {
+    memcpy(r->mt, mt624, sizeof(r->mt));
+    r->idx = 624; /* all 624 words consumed: the next draw regenerates the block */
+}
 /* raw state access: lets tests compare against the product's jump-ahead */
 ORC_API void orc_rng_get_state(const orc_rng *r, uint32_t *mt624, int *idx) {
     memcpy(mt624, r->mt, sizeof(r->mt));

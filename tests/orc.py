@@ -35,6 +35,7 @@ def _load():
     lib.orc_rng_fill_u32.argtypes = [C.c_void_p, _u32p, C.c_uint64]
     lib.orc_rng_fill_double.argtypes = [C.c_void_p, _f64p, C.c_uint64]
     lib.orc_rng_get_state.argtypes = [C.c_void_p, _u32p, C.POINTER(C.c_int)]
+    lib.orc_rng_set_state.argtypes = [C.c_void_p, _u32p]
     lib.orc_build.restype = C.c_void_p
     lib.orc_build.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _i64p, C.c_int]
     lib.orc_scene_free.argtypes = [C.c_void_p]
@@ -92,6 +93,10 @@ class Rng:
 
     def discard(self, n):
         lib.orc_rng_discard(self.h, int(n))
+
+    def set_state(self, mt624):
+        """Continue from a raw window of 624 untempered words (the state preceding the next output)."""
+        lib.orc_rng_set_state(self.h, np.ascontiguousarray(mt624, np.uint32))
 
     def state(self):
         mt = np.empty(624, np.uint32)
