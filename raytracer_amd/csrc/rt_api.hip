@@ -91,6 +91,10 @@ struct rt_ctx {
     DevBuf<int32_t> slot_root;
     DevBuf<uint32_t> leaf_ext;
     DevBuf<double> tris, colors;
+    // camera-relative copies for the packet kernel (rebuilt per render by the prep kernels)
+    DevBuf<rt::DevNode> cam_nodes, cam_tlas;
+    DevBuf<rtk::CamTri> cam_tris;
+    size_t n_nodes = 0, n_tlas = 0;
     int32_t stack_need = 1;
     int64_t n_tris = 0;
     // sampler
@@ -154,6 +158,11 @@ void launch_render(int stack, dim3 grid, hipStream_t st, const rtk::RenderArgs& 
         case 48: hipLaunchKernelGGL((rtk::render_kernel<48, COUNT>), grid, dim3(rtk::NT), 0, st, a); break;
         default: hipLaunchKernelGGL((rtk::render_kernel<0, COUNT>), grid, dim3(rtk::NT), 0, st, a); break;
     }
+}
+
+bool force_per_lane() {
+    const char* e = std::getenv("RT_FORCE_PERLANE");
+    return e && e[0] == '1';
 }
 
 void launch_trace(int stack, dim3 grid, hipStream_t st, const rtk::TraceArgs& a) {
@@ -392,6 +401,9 @@ void rt_destroy(rt_ctx* c) {
     c->leaf_ext.release();
     c->tris.release();
     c->colors.release();
+    c->cam_nodes.release();
+    c->cam_tlas.release();
+    c->cam_tris.release();
     c->d_states.release();
     c->jitter.release();
     c->intensity.release();
@@ -434,6 +446,11 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* scene) {
     if ((rc = c->leaf_ext.ensure(std::max<size_t>(s.leaf_ext.size(), 2)))) return rc;
     if ((rc = c->tris.ensure(s.tris.size()))) return rc;
     if ((rc = c->colors.ensure(s.colors.size()))) return rc;
+    if ((rc = c->cam_nodes.ensure(s.dev_nodes.size()))) return rc;
+    if ((rc = c->cam_tlas.ensure(s.dev_tlas.size()))) return rc;
+    if ((rc = c->cam_tris.ensure(s.prim_mesh.size()))) return rc;
+    c->n_nodes = s.dev_nodes.size();
+    c->n_tlas = s.dev_tlas.size();
     HIP_TRY(hipMemcpyAsync(c->nodes.p, s.dev_nodes.data(), s.dev_nodes.size() * sizeof(rt::DevNode),
                            hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->tlas.p, s.dev_tlas.data(), s.dev_tlas.size() * sizeof(rt::DevNode),
@@ -586,50 +603,95 @@ int rt_render(rt_ctx* c, const rt_render_params* p) {
     }
 
     // ---- traversal ----
-    rtk::RenderArgs a;
-    a.sc = dev_scene(c);
-    for (int i = 0; i < 3; ++i) {
-        a.cam[i] = p->camera_center[i];
-        a.p00[i] = p->pixel_00_center[i];
-    }
-    for (int i = 0; i < 6; ++i) a.sp[i] = p->pixel_spacing[i];
-    a.W = W;
-    a.spp = spp;
-    a.row0 = p->row_begin;
-    a.rows = rows;
-    a.tile_log2 = (spp >= 4) ? 3 : 4;  // >= 256 rays per 8x8 tile from 4 spp on
-    const int ts = 1 << a.tile_log2;
-    a.tiles_x = (W + ts - 1) / ts;
+    const int tile_log2 = (spp >= 4) ? 3 : 4;  // >= 256 rays per 8x8 tile from 4 spp on
+    const int ts = 1 << tile_log2;
+    const int tiles_x = (W + ts - 1) / ts;
     const int tiles_y = (rows + ts - 1) / ts;
-    const int64_t n_tiles = int64_t(a.tiles_x) * tiles_y;
+    const int64_t n_tiles = int64_t(tiles_x) * tiles_y;
     if (n_tiles > 0x7fffffff) return fail(RT_E_LIMIT, "rt_render: too many tiles");
-    a.n_tiles = (int32_t)n_tiles;
-    a.jitter = c->jitter.p;
-    a.intensity = c->intensity.p;
-    a.rgb = c->rgb.p;
-    a.hit_prim = (p->flags & RT_FLAG_HIT_IDS) ? c->hit_prim.p : nullptr;
-    a.hit_t = (p->flags & RT_FLAG_HIT_T) ? c->hit_t.p : nullptr;
-    a.counters = nullptr;
-    a.gstack = nullptr;
-    a.gstack_cap = 0;
-    const int stack = pick_stack(c->stack_need);
-    if (stack == 0) {
-        if ((rc = c->gstack.ensure(size_t(n_tiles) * rtk::NT * size_t(c->stack_need)))) return rc;
-        a.gstack = c->gstack.p;
-        a.gstack_cap = c->stack_need;
-    }
     const bool count = (p->flags & RT_FLAG_COUNTERS) != 0;
-    if (count) {
-        HIP_TRY(hipMemsetAsync(c->counters.p, 0, 4 * sizeof(unsigned long long), c->stream));
-        a.counters = c->counters.p;
+    if (count) HIP_TRY(hipMemsetAsync(c->counters.p, 0, 4 * sizeof(unsigned long long), c->stream));
+    const bool packet = c->stack_need <= rtk::PACKET_STACK && !force_per_lane();
+    if (packet) {
+        // Wave-packet traversal on camera-relative records (see rt_kernels.hip.hpp).
+        const double ox = p->camera_center[0], oy = p->camera_center[1], oz = p->camera_center[2];
+        hipLaunchKernelGGL(rtk::prep_nodes_kernel, dim3((unsigned)((c->n_nodes + 255) / 256)), dim3(256), 0, c->stream,
+                           c->nodes.p, c->cam_nodes.p, (long long)c->n_nodes, ox, oy, oz);
+        hipLaunchKernelGGL(rtk::prep_nodes_kernel, dim3((unsigned)((c->n_tlas + 255) / 256)), dim3(256), 0, c->stream,
+                           c->tlas.p, c->cam_tlas.p, (long long)c->n_tlas, ox, oy, oz);
+        hipLaunchKernelGGL(rtk::prep_tris_kernel, dim3((unsigned)((c->n_tris + 255) / 256)), dim3(256), 0, c->stream,
+                           c->tris.p, c->cam_tris.p, (long long)c->n_tris, ox, oy, oz);
+        HIP_TRY(hipGetLastError());
+        rtk::PacketArgs a;
+        a.sc.nodes = c->cam_nodes.p;
+        a.sc.tlas = c->cam_tlas.p;
+        a.sc.slot_root = c->slot_root.p;
+        a.sc.leaf_ext = c->leaf_ext.p;
+        a.sc.tris = c->cam_tris.p;
+        a.sc.colors = c->colors.p;
+        for (int i = 0; i < 3; ++i) {
+            a.cam[i] = p->camera_center[i];
+            a.p00[i] = p->pixel_00_center[i];
+        }
+        for (int i = 0; i < 6; ++i) a.sp[i] = p->pixel_spacing[i];
+        a.W = W;
+        a.spp = spp;
+        a.row0 = p->row_begin;
+        a.rows = rows;
+        a.tile_log2 = tile_log2;
+        a.tiles_x = tiles_x;
+        a.n_tiles = (int32_t)n_tiles;
+        a.jitter = c->jitter.p;
+        a.intensity = c->intensity.p;
+        a.rgb = c->rgb.p;
+        a.hit_prim = (p->flags & RT_FLAG_HIT_IDS) ? c->hit_prim.p : nullptr;
+        a.hit_t = (p->flags & RT_FLAG_HIT_T) ? c->hit_t.p : nullptr;
+        a.counters = count ? c->counters.p : nullptr;
+        HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+        if (count)
+            hipLaunchKernelGGL(rtk::render_packet_kernel<true>, dim3((unsigned)n_tiles), dim3(rtk::NT), 0, c->stream, a);
+        else
+            hipLaunchKernelGGL(rtk::render_packet_kernel<false>, dim3((unsigned)n_tiles), dim3(rtk::NT), 0, c->stream, a);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    } else {
+        // Per-lane traversal: trees deeper than the packet kernel's 64 pending bits, or forced.
+        rtk::RenderArgs a;
+        a.sc = dev_scene(c);
+        for (int i = 0; i < 3; ++i) {
+            a.cam[i] = p->camera_center[i];
+            a.p00[i] = p->pixel_00_center[i];
+        }
+        for (int i = 0; i < 6; ++i) a.sp[i] = p->pixel_spacing[i];
+        a.W = W;
+        a.spp = spp;
+        a.row0 = p->row_begin;
+        a.rows = rows;
+        a.tile_log2 = tile_log2;
+        a.tiles_x = tiles_x;
+        a.n_tiles = (int32_t)n_tiles;
+        a.jitter = c->jitter.p;
+        a.intensity = c->intensity.p;
+        a.rgb = c->rgb.p;
+        a.hit_prim = (p->flags & RT_FLAG_HIT_IDS) ? c->hit_prim.p : nullptr;
+        a.hit_t = (p->flags & RT_FLAG_HIT_T) ? c->hit_t.p : nullptr;
+        a.counters = count ? c->counters.p : nullptr;
+        a.gstack = nullptr;
+        a.gstack_cap = 0;
+        const int stack = pick_stack(c->stack_need);
+        if (stack == 0) {
+            if ((rc = c->gstack.ensure(size_t(n_tiles) * rtk::NT * size_t(c->stack_need)))) return rc;
+            a.gstack = c->gstack.p;
+            a.gstack_cap = c->stack_need;
+        }
+        HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+        if (count)
+            launch_render<true>(stack, dim3((unsigned)n_tiles), c->stream, a);
+        else
+            launch_render<false>(stack, dim3((unsigned)n_tiles), c->stream, a);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(c->ev[1], c->stream));
     }
-    HIP_TRY(hipEventRecord(c->ev[0], c->stream));
-    if (count)
-        launch_render<true>(stack, dim3((unsigned)n_tiles), c->stream, a);
-    else
-        launch_render<false>(stack, dim3((unsigned)n_tiles), c->stream, a);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
     c->timing_pending = true;
     c->out_rows = rows;
     c->out_w = W;

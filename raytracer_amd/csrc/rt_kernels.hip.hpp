@@ -378,6 +378,404 @@ __global__ __launch_bounds__(NT) void render_kernel(const RenderArgs a) {
     }
 }
 
+
+// =======================================================================================
+// Packet traversal (the render path).
+//
+// All rays of an image share the camera centre, and the reference's visit order does not
+// depend on the ray (always left child first, rtrayintersection.cpp:185-190), so a whole
+// wave can walk the tree together: the walk itself (current node, stack, descriptors, loop
+// control) is wave-uniform and runs on the scalar unit with scalar loads, while each lane
+// only does the slab / Moller-Trumbore arithmetic for its own ray.  A lane takes part in a
+// node's tests iff it passed the slab test of every ancestor -- exactly the nodes the
+// reference pops for that ray -- tracked with one predicate and one pending bit per stack
+// level per lane.  Results are identical to the per-lane walk; the work per node visit drops
+// from ~85 to ~20 vector instructions.
+//
+// Because the origin is shared, everything that depends only on (origin, primitive) is
+// computed once per frame by prep kernels, with the same IEEE operations the reference
+// performs per ray:  node boxes relative to the camera (min-o, max-o), and per triangle
+// e0, e2, tv = o-v0, q = tv x e0 and the t numerator e2.q  (rtrayintersection.cpp:64-72,92,100,105).
+// =======================================================================================
+struct alignas(128) CamTri {
+    double e0[3];
+    double e2[3];
+    double tv[3];
+    double q[3];
+    double tnum;
+    double pad[3];
+};
+static_assert(sizeof(CamTri) == 128, "camera-relative triangle record must be 128 bytes");
+
+__global__ __launch_bounds__(256) void prep_nodes_kernel(const rt::DevNode* __restrict__ in, rt::DevNode* __restrict__ out,
+                                                         const long long n, const double ox, const double oy,
+                                                         const double oz) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    rt::DevNode v = in[i];
+    v.mn[0] = v.mn[0] - ox;
+    v.mn[1] = v.mn[1] - oy;
+    v.mn[2] = v.mn[2] - oz;
+    v.mx[0] = v.mx[0] - ox;
+    v.mx[1] = v.mx[1] - oy;
+    v.mx[2] = v.mx[2] - oz;
+    out[i] = v;
+}
+
+__global__ __launch_bounds__(256) void prep_tris_kernel(const double* __restrict__ tris, CamTri* __restrict__ out,
+                                                        const long long n, const double ox, const double oy,
+                                                        const double oz) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double* tp = tris + (size_t)i * 9;
+    const double v0x = tp[0], v0y = tp[1], v0z = tp[2];
+    CamTri c;
+    c.e0[0] = tp[3] - v0x;
+    c.e0[1] = tp[4] - v0y;
+    c.e0[2] = tp[5] - v0z;
+    c.e2[0] = tp[6] - v0x;
+    c.e2[1] = tp[7] - v0y;
+    c.e2[2] = tp[8] - v0z;
+    c.tv[0] = ox - v0x;
+    c.tv[1] = oy - v0y;
+    c.tv[2] = oz - v0z;
+    c.q[0] = c.tv[1] * c.e0[2] - c.tv[2] * c.e0[1];
+    c.q[1] = c.tv[2] * c.e0[0] - c.tv[0] * c.e0[2];
+    c.q[2] = c.tv[0] * c.e0[1] - c.tv[1] * c.e0[0];
+    c.tnum = (c.e2[0] * c.q[0] + c.e2[1] * c.q[1]) + c.e2[2] * c.q[2];
+    c.pad[0] = c.pad[1] = c.pad[2] = 0.0;
+    out[i] = c;
+}
+
+struct PacketScene {
+    const rt::DevNode* nodes;  // camera-relative boxes
+    const rt::DevNode* tlas;   // camera-relative boxes
+    const int32_t* slot_root;
+    const uint32_t* leaf_ext;
+    const CamTri* tris;
+    const double* colors;
+};
+
+#define RT_CONST __attribute__((address_space(4)))
+typedef const RT_CONST double* cdptr;
+typedef const RT_CONST uint32_t* cuptr;
+
+struct SBox {  // wave-uniform (scalar) camera-relative box
+    double mnx, mny, mnz, mxx, mxy, mxz;
+};
+
+__device__ __forceinline__ void sload_node(const rt::DevNode* p, SBox& b, int32_t& left, int32_t& count,
+                                           int32_t& first, uint32_t& desc) {
+    cdptr q = (cdptr)(const void*)p;
+    b.mnx = q[0];
+    b.mny = q[1];
+    b.mnz = q[2];
+    b.mxx = q[3];
+    b.mxy = q[4];
+    b.mxz = q[5];
+    cuptr m = (cuptr)(const void*)p;
+    left = (int32_t)m[12];
+    count = (int32_t)m[13];
+    first = (int32_t)m[14];
+    desc = m[15];
+}
+
+// slab test against a camera-relative box; FAST uses v_min/v_max (identical to the std::min/
+// std::max composition whenever no operand is NaN: the results are then only compared, and
+// comparisons do not see the sign of a zero).  The caller selects FAST only for waves in which
+// no lane has an infinite inverse-direction component (the only source of 0*inf = NaN).
+template <bool FAST>
+__device__ __forceinline__ bool slab_rel(const SBox& b, const double ix, const double iy, const double iz) {
+    const double t0 = b.mnx * ix, t1 = b.mxx * ix;
+    const double t2 = b.mny * iy, t3 = b.mxy * iy;
+    const double t4 = b.mnz * iz, t5 = b.mxz * iz;
+    double tmin, tmax;
+    if (FAST) {
+        tmin = __builtin_fmax(__builtin_fmax(__builtin_fmin(t0, t1), __builtin_fmin(t2, t3)), __builtin_fmin(t4, t5));
+        tmax = __builtin_fmin(__builtin_fmin(__builtin_fmax(t0, t1), __builtin_fmax(t2, t3)), __builtin_fmax(t4, t5));
+    } else {
+        tmin = std_max(std_max(std_min(t0, t1), std_min(t2, t3)), std_min(t4, t5));
+        tmax = std_min(std_min(std_max(t0, t1), std_max(t2, t3)), std_max(t4, t5));
+    }
+    return tmin <= tmax && tmax > 0.0 && tmin < __builtin_inf();
+}
+
+template <bool FAST, bool COUNT>
+__device__ __forceinline__ void trace_packet(const PacketScene& sc, const bool valid, const double dx, const double dy,
+                                             const double dz, const double ix, const double iy, const double iz,
+                                             uint32_t* wstk, Hit& h, uint32_t& n_nodes, uint32_t& n_tris) {
+    int sp = 0;
+    uint32_t cur = rt::DESC_TLAS;
+    bool in = valid;
+    bool have = true;
+    unsigned long long pend = 0ull;  // bit L: this lane takes part in the entry at stack level L
+    for (;;) {
+        if (!have) {
+            if (sp == 0) break;
+            --sp;
+            cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)wstk[sp]);
+            in = (pend >> sp) & 1ull;
+        }
+        have = false;
+        if (cur & rt::DESC_LEAF) {
+            uint32_t first = cur & rt::DESC_TRI_MASK;
+            uint32_t cnt = ((cur >> 28) & 7u) + 1u;
+            if (cnt == 8u) {
+                cuptr ext = (cuptr)(const void*)sc.leaf_ext;
+                const uint32_t e = first;
+                first = ext[2 * e];
+                cnt = ext[2 * e + 1];
+            }
+            if (COUNT && in) n_tris += cnt;
+            for (uint32_t k = 0; k < cnt; ++k) {
+                cdptr tp = (cdptr)(const void*)(sc.tris + (size_t)(first + k));
+                const double e0x = tp[0], e0y = tp[1], e0z = tp[2];
+                const double e2x = tp[3], e2y = tp[4], e2z = tp[5];
+                const double tvx = tp[6], tvy = tp[7], tvz = tp[8];
+                const double qx = tp[9], qy = tp[10], qz = tp[11];
+                const double tnum = tp[12];
+                // rtrayintersection.cpp:79-106, with the ray-independent parts precomputed
+                const double px = dy * e2z - dz * e2y;
+                const double py = dz * e2x - dx * e2z;
+                const double pz = dx * e2y - dy * e2x;
+                const double det = (e0x * px + e0y * py) + e0z * pz;
+                if (in && det > 1e-6) {
+                    const double inv = 1.0 / det;
+                    const double u = ((tvx * px + tvy * py) + tvz * pz) * inv;
+                    const double v = ((dx * qx + dy * qy) + dz * qz) * inv;
+                    const double t = tnum * inv;
+                    const bool ok = (u >= 0.0) && (u <= 1.0) && (v >= 0.0) && ((u + v) <= 1.0) && (t >= 0.0) &&
+                                    (t <= __builtin_inf());
+                    if (ok && t < h.t) {
+                        h.t = t;
+                        h.u = u;
+                        h.v = v;
+                        h.prim = (int32_t)(first + k);
+                    }
+                }
+            }
+            continue;
+        }
+        if (cur & (rt::DESC_TLAS | rt::DESC_ROOT)) {
+            SBox b;
+            int32_t left, count, first;
+            uint32_t desc;
+            if (cur & rt::DESC_TLAS) {
+                sload_node(sc.tlas + (cur & 0x3FFFFFFFu), b, left, count, first, desc);
+                if (COUNT && in) n_nodes += 1;
+                const bool hit = in && slab_rel<FAST>(b, ix, iy, iz);
+                if (!__any(hit)) continue;
+                if (left < 0) {
+                    for (int32_t k = count - 1; k >= 0; --k) {
+                        wstk[sp] = rt::DESC_ROOT | (uint32_t)(first + k);
+                        pend = hit ? (pend | (1ull << sp)) : (pend & ~(1ull << sp));
+                        ++sp;
+                    }
+                } else {
+                    wstk[sp] = rt::DESC_TLAS | (uint32_t)(left + 1);
+                    pend = hit ? (pend | (1ull << sp)) : (pend & ~(1ull << sp));
+                    ++sp;
+                    wstk[sp] = rt::DESC_TLAS | (uint32_t)left;
+                    pend = hit ? (pend | (1ull << sp)) : (pend & ~(1ull << sp));
+                    ++sp;
+                }
+            } else {
+                const RT_CONST int32_t* sr = (const RT_CONST int32_t*)(const void*)sc.slot_root;
+                const int32_t root = sr[cur & 0x1FFFFFFFu];
+                sload_node(sc.nodes + root, b, left, count, first, desc);
+                if (COUNT && in) n_nodes += 1;
+                const bool hit = in && slab_rel<FAST>(b, ix, iy, iz);
+                if (__any(hit)) {
+                    cur = desc;
+                    in = hit;
+                    have = true;
+                }
+            }
+            continue;
+        }
+        // internal BLAS node: both children in one 128-byte scalar fetch
+        SBox bl, br;
+        int32_t l0, l1, l2, r0, r1, r2;
+        uint32_t dl, dr;
+        sload_node(sc.nodes + cur, bl, l0, l1, l2, dl);
+        sload_node(sc.nodes + cur + 1, br, r0, r1, r2, dr);
+        if (COUNT && in) n_nodes += 2;
+        const bool hl = in && slab_rel<FAST>(bl, ix, iy, iz);
+        const bool hr = in && slab_rel<FAST>(br, ix, iy, iz);
+        const bool anyl = __any(hl), anyr = __any(hr);
+        if (anyl) {
+            if (anyr) {
+                wstk[sp] = dr;
+                pend = hr ? (pend | (1ull << sp)) : (pend & ~(1ull << sp));
+                ++sp;
+            }
+            cur = dl;
+            in = hl;
+            have = true;
+        } else if (anyr) {
+            cur = dr;
+            in = hr;
+            have = true;
+        }
+    }
+}
+
+struct PacketArgs {
+    PacketScene sc;
+    double cam[3], p00[3], sp[6];
+    int32_t W, spp;
+    int32_t row0, rows;
+    int32_t tile_log2;
+    int32_t tiles_x, n_tiles;
+    const double* jitter;
+    double* intensity;
+    uint8_t* rgb;
+    int32_t* hit_prim;
+    double* hit_t;
+    unsigned long long* counters;
+};
+
+constexpr int PACKET_STACK = 64;  // pending bits live in one 64-bit register per lane
+
+template <bool COUNT>
+__global__ __launch_bounds__(NT) void render_packet_kernel(const PacketArgs a) {
+    __shared__ uint32_t s_wstk[NT / 64][PACKET_STACK];
+    __shared__ double s_col[3][NT];
+    __shared__ double s_acc[3][NT];
+
+    const int tid = threadIdx.x;
+    int tile = blockIdx.x;
+    {
+        const int nb = a.n_tiles, per = nb >> 3, main = per << 3;
+        if ((int)blockIdx.x < main) tile = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+    }
+    const int ts = 1 << a.tile_log2;
+    const int npix_tile = ts * ts;
+    const int tx0 = (tile % a.tiles_x) << a.tile_log2;
+    const int ty0 = (tile / a.tiles_x) << a.tile_log2;
+    const int spp = a.spp;
+    const int n_rays = npix_tile * spp;
+    uint32_t* wstk = s_wstk[tid >> 6];
+
+    s_acc[0][tid] = 0.0;
+    s_acc[1][tid] = 0.0;
+    s_acc[2][tid] = 0.0;
+
+    uint32_t n_nodes = 0, n_tris = 0, n_hits = 0;
+
+    for (int base = 0; base < n_rays; base += NT) {
+        const int rr = base + tid;
+        const int m = rr / spp;
+        const int k = rr - m * spp;
+        const int px = tx0 + (int)compact1by1((uint32_t)m);
+        const int py = ty0 + (int)compact1by1((uint32_t)m >> 1);
+        const bool active = (rr < n_rays) && (px < a.W) && (py < a.rows);
+        double c0 = 0.0, c1 = 0.0, c2 = 0.0;
+        const size_t sidx = active ? ((size_t)py * a.W + px) * (size_t)spp + k : 0;
+        double dx = 0.0, dy = 0.0, dz = -1.0;
+        if (active) {
+            const d2 jit = reinterpret_cast<const d2*>(a.jitter)[sidx];
+            const double s0 = (double)px + jit.x;
+            const double s1 = (double)(py + a.row0) + jit.y;
+            const double ddx = ((a.p00[0] + s0 * a.sp[0]) + s1 * a.sp[3]) - a.cam[0];
+            const double ddy = ((a.p00[1] + s0 * a.sp[1]) + s1 * a.sp[4]) - a.cam[1];
+            const double ddz = ((a.p00[2] + s0 * a.sp[2]) + s1 * a.sp[5]) - a.cam[2];
+            const double z = (ddx * ddx + ddy * ddy) + ddz * ddz;
+            dx = ddx;
+            dy = ddy;
+            dz = ddz;
+            if (z > 0.0) {
+                const double nz = __builtin_sqrt(z);
+                dx = ddx / nz;
+                dy = ddy / nz;
+                dz = ddz / nz;
+            }
+        }
+        const double ix = 1.0 / dx, iy = 1.0 / dy, iz = 1.0 / dz;
+        Hit h;
+        h.t = __builtin_inf();
+        h.u = 0.0;
+        h.v = 0.0;
+        h.prim = -1;
+        const bool risky = active && (__builtin_isinf(ix) || __builtin_isinf(iy) || __builtin_isinf(iz));
+        if (__any(active)) {
+            if (__any(risky))
+                trace_packet<false, COUNT>(a.sc, active, dx, dy, dz, ix, iy, iz, wstk, h, n_nodes, n_tris);
+            else
+                trace_packet<true, COUNT>(a.sc, active, dx, dy, dz, ix, iy, iz, wstk, h, n_nodes, n_tris);
+        }
+        if (active) {
+            if (h.t != __builtin_inf()) {
+                const double* fc = a.sc.colors + (size_t)h.prim * 3;
+                const double w = (1.0 - h.u) - h.v;
+                const double f0 = fc[0], f1 = fc[1], f2 = fc[2];
+                c0 = (h.u * f0 + h.v * f0) + w * f0;
+                c1 = (h.u * f1 + h.v * f1) + w * f1;
+                c2 = (h.u * f2 + h.v * f2) + w * f2;
+            } else {
+                const double al = 0.5 * (dy + 1.0);
+                const double ia = (1.0 - al) * 1.0;
+                c0 = ia + al * 0.5;
+                c1 = ia + al * 0.7;
+                c2 = ia + al * 1.0;
+            }
+            if (COUNT) n_hits += (h.prim >= 0);
+            if (a.hit_prim) a.hit_prim[sidx] = h.prim;
+            if (a.hit_t) a.hit_t[sidx] = h.t;
+        }
+        s_col[0][tid] = c0;
+        s_col[1][tid] = c1;
+        s_col[2][tid] = c2;
+        __syncthreads();
+        {
+            const int end = min(base + NT, n_rays);
+            const int m_first = base / spp;
+            const int m_last = (end - 1) / spp;
+            const int work = (m_last - m_first + 1) * 3;
+            for (int q = tid; q < work; q += NT) {
+                const int pm = m_first + q / 3;
+                const int c = q - (q / 3) * 3;
+                const int lo = max(pm * spp, base) - base;
+                const int hi = min((pm + 1) * spp, end) - base;
+                double acc = s_acc[c][pm];
+                for (int s = lo; s < hi; ++s) acc += s_col[c][s];
+                s_acc[c][pm] = acc;
+            }
+        }
+        __syncthreads();
+    }
+
+    if (tid < npix_tile) {
+        const int px = tx0 + (int)compact1by1((uint32_t)tid);
+        const int py = ty0 + (int)compact1by1((uint32_t)tid >> 1);
+        if (px < a.W && py < a.rows) {
+            const double gray = (0.2126 * s_acc[0][tid] + 0.7152 * s_acc[1][tid]) + 0.0722 * s_acc[2][tid];
+            const double inten = gray / (double)spp;
+            const int gb = (int)(inten * 255.99);
+            const size_t pidx = (size_t)py * a.W + px;
+            a.intensity[pidx] = inten;
+            const uint8_t g8 = (uint8_t)gb;
+            a.rgb[pidx * 3] = g8;
+            a.rgb[pidx * 3 + 1] = g8;
+            a.rgb[pidx * 3 + 2] = g8;
+        }
+    }
+
+    if (COUNT) {
+        unsigned long long v0 = n_nodes, v1 = n_tris, v2 = n_hits;
+        for (int off = 32; off > 0; off >>= 1) {
+            v0 += __shfl_down(v0, off, 64);
+            v1 += __shfl_down(v1, off, 64);
+            v2 += __shfl_down(v2, off, 64);
+        }
+        if ((tid & 63) == 0 && a.counters) {
+            atomicAdd(&a.counters[0], v0);
+            atomicAdd(&a.counters[1], v1);
+            atomicAdd(&a.counters[2], v2);
+        }
+    }
+}
+
 struct TraceArgs {
     DevScene sc;
     long long n;
