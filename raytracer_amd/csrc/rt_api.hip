@@ -101,17 +101,24 @@ struct rt_ctx {
     uint32_t seed = 5489u;
     uint64_t pos = 0;   // position of the global stream, in 32-bit outputs
     rt::MtState state;  // state preceding `pos`
-    // look-ahead: stream states computed for a predicted next call while the GPU is busy
-    struct Prefetch {
+    // Jitter slots: the pairs for one launch each.  While the traversal kernel of call n reads
+    // slot A, the jitter kernel for the predicted call n+1 fills slot B on rng_stream.
+    struct JitterSlot {
+        DevBuf<double> buf;
+        DevBuf<uint32_t> d_states;
+        std::vector<rt::MtState> states;  // host copy: must outlive the async H2D copy
         bool valid = false;
-        uint64_t pos = 0, stride = 0;
-        int n = 0;
-        std::vector<rt::MtState> states;
-        rt::MtState end_state;  // state preceding pos + total_words
-        uint64_t total_words = 0;
-    } pre;
-    DevBuf<uint32_t> d_states;
-    DevBuf<double> jitter;
+        uint64_t pos = 0;  // stream position the slot starts at
+        int rows = 0, W = 0, spp = 0;
+        rt::MtState end_state;  // state preceding pos + rows*W*spp*4
+        hipEvent_t done = nullptr, t0 = nullptr, t1 = nullptr;
+        double host_ms = 0.0;
+    } slot[2];
+    int last_slot = 0;
+    bool have_last_start = false;
+    uint64_t last_start = 0;
+    DevBuf<uint32_t> d_states;  // rt_rng_jitter only
+    DevBuf<double> jitter;      // rt_rng_jitter only
     // outputs of the last render
     DevBuf<double> intensity, hit_t;
     DevBuf<uint8_t> rgb;
@@ -205,14 +212,39 @@ void compute_states(const rt::MtState& base, const StreamPlan& pl, std::vector<r
     rt::mt_apply(rt::mt_jump_poly(rem), states[pl.n - 1], end_state);
 }
 
-int launch_jitter(rt_ctx* c, const std::vector<rt::MtState>& states, const StreamPlan& pl, double* d_out,
-                  hipStream_t st) {
-    int rc = c->d_states.ensure(size_t(pl.n) * rt::MT_N);
+int launch_jitter(DevBuf<uint32_t>& d_states, const std::vector<rt::MtState>& states, const StreamPlan& pl,
+                  double* d_out, hipStream_t st) {
+    int rc = d_states.ensure(size_t(pl.n) * rt::MT_N);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(c->d_states.p, states.data(), size_t(pl.n) * sizeof(rt::MtState), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(rtk::mt_jitter_kernel, dim3(pl.n), dim3(64), 0, st, c->d_states.p, d_out,
+    HIP_TRY(hipMemcpyAsync(d_states.p, states.data(), size_t(pl.n) * sizeof(rt::MtState), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(rtk::mt_jitter_kernel, dim3(pl.n), dim3(64), 0, st, d_states.p, d_out,
                        (unsigned long long)(pl.stride / 2), (unsigned long long)(pl.total_words / 2));
     HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+// Generate the jitter of one launch (rows x W x spp samples starting at stream position `pos`,
+// whose preceding state is `base`) into slot `k` on rng_stream.
+int fill_slot(rt_ctx* c, int k, const rt::MtState& base, uint64_t pos, int rows, int W, int spp) {
+    rt_ctx::JitterSlot& sl = c->slot[k];
+    sl.valid = false;
+    const size_t n_smp = size_t(rows) * size_t(W) * size_t(spp);
+    int rc = sl.buf.ensure(n_smp * 2);
+    if (rc) return rc;
+    const StreamPlan pl = plan_streams(rows, W, spp);
+    const double t0 = now_ms();
+    compute_states(base, pl, sl.states, sl.end_state);
+    sl.host_ms = now_ms() - t0;
+    HIP_TRY(hipEventRecord(sl.t0, c->rng_stream));
+    rc = launch_jitter(sl.d_states, sl.states, pl, sl.buf.p, c->rng_stream);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(sl.t1, c->rng_stream));
+    HIP_TRY(hipEventRecord(sl.done, c->rng_stream));
+    sl.pos = pos;
+    sl.rows = rows;
+    sl.W = W;
+    sl.spp = spp;
+    sl.valid = true;
     return RT_OK;
 }
 
@@ -385,6 +417,12 @@ rt_ctx* rt_create(int device) {
             g_err = "rt_create: hipEventCreate failed";
             return nullptr;
         }
+    for (auto& sl : c->slot)
+        if (hipEventCreate(&sl.done) != hipSuccess || hipEventCreate(&sl.t0) != hipSuccess ||
+            hipEventCreate(&sl.t1) != hipSuccess) {
+            g_err = "rt_create: hipEventCreate failed";
+            return nullptr;
+        }
     rt::mt_seed(c->state, c->seed);
     c->pos = 0;
     return c.release();
@@ -406,6 +444,13 @@ void rt_destroy(rt_ctx* c) {
     c->cam_tris.release();
     c->d_states.release();
     c->jitter.release();
+    for (auto& sl : c->slot) {
+        sl.buf.release();
+        sl.d_states.release();
+        if (sl.done) (void)hipEventDestroy(sl.done);
+        if (sl.t0) (void)hipEventDestroy(sl.t0);
+        if (sl.t1) (void)hipEventDestroy(sl.t1);
+    }
     c->intensity.release();
     c->hit_t.release();
     c->rgb.release();
@@ -478,7 +523,8 @@ int rt_rng_seed(rt_ctx* c, uint32_t seed) {
     c->seed = seed;
     rt::mt_seed(c->state, seed);
     c->pos = 0;
-    c->pre.valid = false;
+    for (auto& sl : c->slot) sl.valid = false;  // slots belong to the old seed's stream
+    c->have_last_start = false;
     return RT_OK;
 }
 
@@ -519,13 +565,12 @@ int rt_rng_jitter(rt_ctx* c, int64_t n, int n_streams, double* out_host) {
         compute_states(c->state, pl, states, end_state);
         int rc = c->jitter.ensure(size_t(n));
         if (rc) return rc;
-        rc = launch_jitter(c, states, pl, c->jitter.p, c->rng_stream);
+        rc = launch_jitter(c->d_states, states, pl, c->jitter.p, c->rng_stream);
         if (rc) return rc;
         HIP_TRY(hipMemcpyAsync(out_host, c->jitter.p, size_t(n) * sizeof(double), hipMemcpyDeviceToHost, c->rng_stream));
         HIP_TRY(hipStreamSynchronize(c->rng_stream));
         c->state = end_state;
         c->pos += pl.total_words;
-        c->pre.valid = false;
     } catch (const std::exception& e) {
         return fail(RT_E_INVALID, e.what());
     }
@@ -554,7 +599,6 @@ int rt_render(rt_ctx* c, const rt_render_params* p) {
     HIP_TRY(hipStreamSynchronize(c->rng_stream));
 
     int rc;
-    if ((rc = c->jitter.ensure(n_smp * 2))) return rc;
     if ((rc = c->intensity.ensure(n_pix))) return rc;
     if ((rc = c->rgb.ensure(n_pix * 3))) return rc;
     if (p->flags & RT_FLAG_HIT_IDS)
@@ -568,39 +612,37 @@ int rt_render(rt_ctx* c, const rt_render_params* p) {
     c->jitter_timed = false;
 
     // ---- jitter ----
+    int use = 0;
+    const uint64_t start_pos = c->pos;
     if (p->sampler == RT_SAMPLER_EXPLICIT) {
-        HIP_TRY(hipMemcpyAsync(c->jitter.p, p->jitter, n_smp * 2 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        use = 0;
+        c->slot[0].valid = false;
+        if ((rc = c->slot[0].buf.ensure(n_smp * 2))) return rc;
+        HIP_TRY(hipMemcpyAsync(c->slot[0].buf.p, p->jitter, n_smp * 2 * sizeof(double), hipMemcpyHostToDevice,
+                               c->stream));
     } else {
         try {
-            const StreamPlan pl = plan_streams(rows, W, spp);
-            const double t0 = now_ms();
-            std::vector<rt::MtState> local_states;
-            rt::MtState end_state;
-            const std::vector<rt::MtState>* states = &local_states;
-            if (c->pre.valid && c->pre.pos == c->pos && c->pre.stride == pl.stride && c->pre.n == pl.n &&
-                c->pre.total_words == pl.total_words) {
-                states = &c->pre.states;
-                end_state = c->pre.end_state;
-            } else {
-                compute_states(c->state, pl, local_states, end_state);
+            use = -1;
+            for (int k = 0; k < 2; ++k) {
+                const auto& sl = c->slot[k];
+                if (sl.valid && sl.pos == c->pos && sl.rows == rows && sl.W == W && sl.spp == spp) use = k;
             }
-            c->stats.host_jump_ms = now_ms() - t0;
-            HIP_TRY(hipEventRecord(c->ev[2], c->rng_stream));
-            rc = launch_jitter(c, *states, pl, c->jitter.p, c->rng_stream);
-            if (rc) return rc;
-            HIP_TRY(hipEventRecord(c->ev[3], c->rng_stream));
-            HIP_TRY(hipEventRecord(c->ev[4], c->rng_stream));
-            HIP_TRY(hipStreamWaitEvent(c->stream, c->ev[4], 0));
+            if (use < 0) {
+                use = 1 - c->last_slot;
+                if ((rc = fill_slot(c, use, c->state, c->pos, rows, W, spp))) return rc;
+                c->stats.host_jump_ms = c->slot[use].host_ms;
+            }
+            HIP_TRY(hipStreamWaitEvent(c->stream, c->slot[use].done, 0));
             c->jitter_timed = true;
-            c->state = end_state;
-            c->pos += pl.total_words;
-            if (states == &c->pre.states) {
-                // keep the vector alive until the H2D copy has been staged: it is consumed below
-            }
+            c->state = c->slot[use].end_state;
+            c->pos += uint64_t(n_smp) * 4u;
+            c->slot[use].valid = false;  // consumed
+            c->last_slot = use;
         } catch (const std::exception& e) {
             return fail(RT_E_INVALID, std::string("rt_render: sampler: ") + e.what());
         }
     }
+    const double* d_jitter = c->slot[use].buf.p;
 
     // ---- traversal ----
     const int tile_log2 = (spp >= 4) ? 3 : 4;  // >= 256 rays per 8x8 tile from 4 spp on
@@ -641,7 +683,7 @@ int rt_render(rt_ctx* c, const rt_render_params* p) {
         a.tile_log2 = tile_log2;
         a.tiles_x = tiles_x;
         a.n_tiles = (int32_t)n_tiles;
-        a.jitter = c->jitter.p;
+        a.jitter = d_jitter;
         a.intensity = c->intensity.p;
         a.rgb = c->rgb.p;
         a.hit_prim = (p->flags & RT_FLAG_HIT_IDS) ? c->hit_prim.p : nullptr;
@@ -670,7 +712,7 @@ int rt_render(rt_ctx* c, const rt_render_params* p) {
         a.tile_log2 = tile_log2;
         a.tiles_x = tiles_x;
         a.n_tiles = (int32_t)n_tiles;
-        a.jitter = c->jitter.p;
+        a.jitter = d_jitter;
         a.intensity = c->intensity.p;
         a.rgb = c->rgb.p;
         a.hit_prim = (p->flags & RT_FLAG_HIT_IDS) ? c->hit_prim.p : nullptr;
@@ -698,22 +740,27 @@ int rt_render(rt_ctx* c, const rt_render_params* p) {
     c->out_spp = spp;
     c->out_flags = p->flags;
 
-    // ---- look-ahead: jump-ahead states for an identical next call, while the GPU works ----
-    if (p->sampler == RT_SAMPLER_MT19937) {
+    // ---- look-ahead: while the GPU traverses, generate the jitter of the predicted next call
+    // (same shape; same distance between starts as the last two calls, else contiguous) into the
+    // other slot.  A wrong guess costs nothing but the wasted work.
+    if (p->sampler == RT_SAMPLER_MT19937 && !std::getenv("RT_NO_LOOKAHEAD")) {
         try {
-            // the H2D copy of the states used above must have been staged before we overwrite them
-            HIP_TRY(hipEventSynchronize(c->ev[4]));
-            const StreamPlan pl = plan_streams(rows, W, spp);
-            c->pre.valid = false;
-            compute_states(c->state, pl, c->pre.states, c->pre.end_state);
-            c->pre.pos = c->pos;
-            c->pre.stride = pl.stride;
-            c->pre.n = pl.n;
-            c->pre.total_words = pl.total_words;
-            c->pre.valid = true;
+            uint64_t next = c->pos;
+            if (c->have_last_start && start_pos > c->last_start) {
+                const uint64_t delta = start_pos - c->last_start;
+                if (delta >= uint64_t(n_smp) * 4u) next = start_pos + delta;
+            }
+            rt::MtState base = c->state;
+            if (next != c->pos) rt::mt_apply(rt::mt_jump_poly(next - c->pos), c->state, base);
+            const int other = 1 - use;
+            // slot `other` was last read by the previous call's kernel, which has completed
+            // (stream synchronised on entry); its own jitter kernel is ordered on rng_stream.
+            if ((rc = fill_slot(c, other, base, next, rows, W, spp))) return rc;
         } catch (const std::exception&) {
-            c->pre.valid = false;
+            c->slot[1 - use].valid = false;
         }
+        c->have_last_start = true;
+        c->last_start = start_pos;
     }
     return RT_OK;
 }
@@ -728,8 +775,9 @@ int rt_last_stats(const rt_ctx* cc, rt_stats* out) {
         HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
         c->stats.render_kernel_ms = ms;
         if (c->jitter_timed) {
-            HIP_TRY(hipEventSynchronize(c->ev[3]));
-            HIP_TRY(hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
+            rt_ctx::JitterSlot& sl = c->slot[c->last_slot];
+            HIP_TRY(hipEventSynchronize(sl.t1));
+            HIP_TRY(hipEventElapsedTime(&ms, sl.t0, sl.t1));
             c->stats.jitter_kernel_ms = ms;
         }
         if (c->out_flags & RT_FLAG_COUNTERS) {

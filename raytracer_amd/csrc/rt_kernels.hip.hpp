@@ -485,7 +485,7 @@ __device__ __forceinline__ void sload_node(const rt::DevNode* p, SBox& b, int32_
 // comparisons do not see the sign of a zero).  The caller selects FAST only for waves in which
 // no lane has an infinite inverse-direction component (the only source of 0*inf = NaN).
 template <bool FAST>
-__device__ __forceinline__ bool slab_rel(const SBox& b, const double ix, const double iy, const double iz) {
+__device__ __forceinline__ unsigned long long slab_rel(const SBox& b, const double ix, const double iy, const double iz) {
     const double t0 = b.mnx * ix, t1 = b.mxx * ix;
     const double t2 = b.mny * iy, t3 = b.mxy * iy;
     const double t4 = b.mnz * iz, t5 = b.mxz * iz;
@@ -497,24 +497,36 @@ __device__ __forceinline__ bool slab_rel(const SBox& b, const double ix, const d
         tmin = std_max(std_max(std_min(t0, t1), std_min(t2, t3)), std_min(t4, t5));
         tmax = std_min(std_min(std_max(t0, t1), std_max(t2, t3)), std_max(t4, t5));
     }
-    return tmin <= tmax && tmax > 0.0 && tmin < __builtin_inf();
+    // one ballot per comparison: each v_cmp writes its lane mask straight into an SGPR pair and the
+    // masks are combined on the scalar unit
+    return __builtin_amdgcn_ballot_w64(tmin <= tmax) & __builtin_amdgcn_ballot_w64(tmax > 0.0) &
+           __builtin_amdgcn_ballot_w64(tmin < __builtin_inf());
 }
 
+// The set of lanes taking part in the current node is a wave-uniform 64-bit mask (SGPR pair);
+// stack entries carry the mask of lanes that passed the pushed node's slab test.
+struct WaveCounters {
+    unsigned long long nodes, tris;  // wave-uniform sums over participating lanes
+};
+
 template <bool FAST, bool COUNT>
-__device__ __forceinline__ void trace_packet(const PacketScene& sc, const bool valid, const double dx, const double dy,
-                                             const double dz, const double ix, const double iy, const double iz,
-                                             uint32_t* wstk, Hit& h, uint32_t& n_nodes, uint32_t& n_tris) {
+__device__ __forceinline__ void trace_packet(const PacketScene& sc, const unsigned long long valid_mask,
+                                             const double dx, const double dy, const double dz, const double ix,
+                                             const double iy, const double iz, uint4* wstk, Hit& h,
+                                             WaveCounters& wc) {
     int sp = 0;
     uint32_t cur = rt::DESC_TLAS;
-    bool in = valid;
+    unsigned long long inm = valid_mask;
     bool have = true;
-    unsigned long long pend = 0ull;  // bit L: this lane takes part in the entry at stack level L
     for (;;) {
         if (!have) {
             if (sp == 0) break;
             --sp;
-            cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)wstk[sp]);
-            in = (pend >> sp) & 1ull;
+            const uint4 e = wstk[sp];
+            cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.x);
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.y);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.z);
+            inm = ((unsigned long long)hi << 32) | lo;
         }
         have = false;
         if (cur & rt::DESC_LEAF) {
@@ -526,7 +538,8 @@ __device__ __forceinline__ void trace_packet(const PacketScene& sc, const bool v
                 first = ext[2 * e];
                 cnt = ext[2 * e + 1];
             }
-            if (COUNT && in) n_tris += cnt;
+            if (COUNT) wc.tris += (unsigned long long)cnt * (unsigned)__builtin_popcountll(inm);
+            const bool in = __builtin_amdgcn_inverse_ballot_w64(inm);
             for (uint32_t k = 0; k < cnt; ++k) {
                 cdptr tp = (cdptr)(const void*)(sc.tris + (size_t)(first + k));
                 const double e0x = tp[0], e0y = tp[1], e0z = tp[2];
@@ -562,59 +575,66 @@ __device__ __forceinline__ void trace_packet(const PacketScene& sc, const bool v
             uint32_t desc;
             if (cur & rt::DESC_TLAS) {
                 sload_node(sc.tlas + (cur & 0x3FFFFFFFu), b, left, count, first, desc);
-                if (COUNT && in) n_nodes += 1;
-                const bool hit = in && slab_rel<FAST>(b, ix, iy, iz);
-                if (!__any(hit)) continue;
+                if (COUNT) wc.nodes += (unsigned)__builtin_popcountll(inm);
+                const unsigned long long hm = slab_rel<FAST>(b, ix, iy, iz) & inm;
+                if (hm == 0ull) continue;
+                const uint32_t lo = (uint32_t)hm, hi = (uint32_t)(hm >> 32);
                 if (left < 0) {
-                    for (int32_t k = count - 1; k >= 0; --k) {
-                        wstk[sp] = rt::DESC_ROOT | (uint32_t)(first + k);
-                        pend = hit ? (pend | (1ull << sp)) : (pend & ~(1ull << sp));
-                        ++sp;
-                    }
+                    for (int32_t k = count - 1; k >= 0; --k) wstk[sp++] = make_uint4(rt::DESC_ROOT | (uint32_t)(first + k), lo, hi, 0u);
                 } else {
-                    wstk[sp] = rt::DESC_TLAS | (uint32_t)(left + 1);
-                    pend = hit ? (pend | (1ull << sp)) : (pend & ~(1ull << sp));
-                    ++sp;
-                    wstk[sp] = rt::DESC_TLAS | (uint32_t)left;
-                    pend = hit ? (pend | (1ull << sp)) : (pend & ~(1ull << sp));
-                    ++sp;
+                    wstk[sp++] = make_uint4(rt::DESC_TLAS | (uint32_t)(left + 1), lo, hi, 0u);
+                    wstk[sp++] = make_uint4(rt::DESC_TLAS | (uint32_t)left, lo, hi, 0u);
                 }
             } else {
                 const RT_CONST int32_t* sr = (const RT_CONST int32_t*)(const void*)sc.slot_root;
                 const int32_t root = sr[cur & 0x1FFFFFFFu];
                 sload_node(sc.nodes + root, b, left, count, first, desc);
-                if (COUNT && in) n_nodes += 1;
-                const bool hit = in && slab_rel<FAST>(b, ix, iy, iz);
-                if (__any(hit)) {
+                if (COUNT) wc.nodes += (unsigned)__builtin_popcountll(inm);
+                const unsigned long long hm = slab_rel<FAST>(b, ix, iy, iz) & inm;
+                if (hm != 0ull) {
                     cur = desc;
-                    in = hit;
+                    inm = hm;
                     have = true;
                 }
             }
             continue;
         }
-        // internal BLAS node: both children in one 128-byte scalar fetch
+        // internal BLAS node: both children in one 128-byte scalar fetch, tested unconditionally
+        // (lanes outside `inm` compute garbage that the mask discards)
         SBox bl, br;
-        int32_t l0, l1, l2, r0, r1, r2;
         uint32_t dl, dr;
-        sload_node(sc.nodes + cur, bl, l0, l1, l2, dl);
-        sload_node(sc.nodes + cur + 1, br, r0, r1, r2, dr);
-        if (COUNT && in) n_nodes += 2;
-        const bool hl = in && slab_rel<FAST>(bl, ix, iy, iz);
-        const bool hr = in && slab_rel<FAST>(br, ix, iy, iz);
-        const bool anyl = __any(hl), anyr = __any(hr);
-        if (anyl) {
-            if (anyr) {
-                wstk[sp] = dr;
-                pend = hr ? (pend | (1ull << sp)) : (pend & ~(1ull << sp));
-                ++sp;
-            }
+        {
+            cdptr q = (cdptr)(const void*)(sc.nodes + cur);
+            bl.mnx = q[0];
+            bl.mny = q[1];
+            bl.mnz = q[2];
+            bl.mxx = q[3];
+            bl.mxy = q[4];
+            bl.mxz = q[5];
+            br.mnx = q[8];
+            br.mny = q[9];
+            br.mnz = q[10];
+            br.mxx = q[11];
+            br.mxy = q[12];
+            br.mxz = q[13];
+            cuptr m = (cuptr)(const void*)(sc.nodes + cur);
+            dl = m[15];
+            dr = m[31];
+            // keep both descriptors in the one batch of scalar loads (hipcc otherwise sinks the
+            // load of the taken child's descriptor behind the branch: a second latency per step)
+            asm volatile("" : "+s"(dl), "+s"(dr));
+        }
+        if (COUNT) wc.nodes += 2u * (unsigned)__builtin_popcountll(inm);
+        const unsigned long long ml = slab_rel<FAST>(bl, ix, iy, iz) & inm;
+        const unsigned long long mr = slab_rel<FAST>(br, ix, iy, iz) & inm;
+        if (ml != 0ull) {
+            if (mr != 0ull) wstk[sp++] = make_uint4(dr, (uint32_t)mr, (uint32_t)(mr >> 32), 0u);
             cur = dl;
-            in = hl;
+            inm = ml;
             have = true;
-        } else if (anyr) {
+        } else if (mr != 0ull) {
             cur = dr;
-            in = hr;
+            inm = mr;
             have = true;
         }
     }
@@ -635,11 +655,11 @@ struct PacketArgs {
     unsigned long long* counters;
 };
 
-constexpr int PACKET_STACK = 64;  // pending bits live in one 64-bit register per lane
+constexpr int PACKET_STACK = 128;  // entries of the per-wave LDS stack ({descriptor, lane mask}, 16 B each)
 
 template <bool COUNT>
 __global__ __launch_bounds__(NT) void render_packet_kernel(const PacketArgs a) {
-    __shared__ uint32_t s_wstk[NT / 64][PACKET_STACK];
+    __shared__ uint4 s_wstk[NT / 64][PACKET_STACK];
     __shared__ double s_col[3][NT];
     __shared__ double s_acc[3][NT];
 
@@ -655,13 +675,14 @@ __global__ __launch_bounds__(NT) void render_packet_kernel(const PacketArgs a) {
     const int ty0 = (tile / a.tiles_x) << a.tile_log2;
     const int spp = a.spp;
     const int n_rays = npix_tile * spp;
-    uint32_t* wstk = s_wstk[tid >> 6];
+    uint4* wstk = s_wstk[tid >> 6];
 
     s_acc[0][tid] = 0.0;
     s_acc[1][tid] = 0.0;
     s_acc[2][tid] = 0.0;
 
-    uint32_t n_nodes = 0, n_tris = 0, n_hits = 0;
+    unsigned long long w_nodes = 0, w_tris = 0;  // lane 0 of each wave carries the wave's sums
+    uint32_t n_hits = 0;
 
     for (int base = 0; base < n_rays; base += NT) {
         const int rr = base + tid;
@@ -698,11 +719,17 @@ __global__ __launch_bounds__(NT) void render_packet_kernel(const PacketArgs a) {
         h.v = 0.0;
         h.prim = -1;
         const bool risky = active && (__builtin_isinf(ix) || __builtin_isinf(iy) || __builtin_isinf(iz));
-        if (__any(active)) {
-            if (__any(risky))
-                trace_packet<false, COUNT>(a.sc, active, dx, dy, dz, ix, iy, iz, wstk, h, n_nodes, n_tris);
+        const unsigned long long amask = __builtin_amdgcn_ballot_w64(active);
+        if (amask != 0ull) {
+            WaveCounters wc = {0ull, 0ull};
+            if (__builtin_amdgcn_ballot_w64(risky) != 0ull)
+                trace_packet<false, COUNT>(a.sc, amask, dx, dy, dz, ix, iy, iz, wstk, h, wc);
             else
-                trace_packet<true, COUNT>(a.sc, active, dx, dy, dz, ix, iy, iz, wstk, h, n_nodes, n_tris);
+                trace_packet<true, COUNT>(a.sc, amask, dx, dy, dz, ix, iy, iz, wstk, h, wc);
+            if (COUNT && (tid & 63) == 0) {
+                w_nodes += wc.nodes;
+                w_tris += wc.tris;
+            }
         }
         if (active) {
             if (h.t != __builtin_inf()) {
@@ -762,7 +789,7 @@ __global__ __launch_bounds__(NT) void render_packet_kernel(const PacketArgs a) {
     }
 
     if (COUNT) {
-        unsigned long long v0 = n_nodes, v1 = n_tris, v2 = n_hits;
+        unsigned long long v0 = w_nodes, v1 = w_tris, v2 = n_hits;
         for (int off = 32; off > 0; off >>= 1) {
             v0 += __shfl_down(v0, off, 64);
             v1 += __shfl_down(v1, off, 64);
@@ -856,22 +883,39 @@ __global__ __launch_bounds__(64) void mt_jitter_kernel(const uint32_t* __restric
     unsigned long long pos = stream * doubles_per_stream;
     unsigned long long end = pos + doubles_per_stream;
     if (end > total_doubles) end = total_doubles;
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
     for (; pos < end; pos += 312) {
-        for (int c = 0; c < 10; ++c) {
-            const int k = c * 64 + lane;
-            uint32_t nw = 0;
-            if (k < 624) {
-                const uint32_t xa = x[k];
-                const uint32_t xb = x[(k + 1 == 624) ? 0 : k + 1];
-                const uint32_t xm = x[(k + 397 >= 624) ? k + 397 - 624 : k + 397];
+        // Two 64-word chunks per step: element k of the new block reads x[k], x[k+1] and
+        // x[k+397 mod 624]; the newest word any of the 128 elements of a step needs was produced
+        // >= 227-128 = 99 elements earlier, i.e. in a previous step, so the pair is independent
+        // and its six LDS reads are in flight together (this kernel runs one wave per CU and is
+        // bound by LDS latency, not throughput).
+#pragma unroll
+        for (int c = 0; c < 10; c += 2) {
+            const int k0 = c * 64 + lane, k1 = k0 + 64;
+            uint32_t n0 = 0, n1 = 0;
+            {
+                const uint32_t xa = x[k0];
+                const uint32_t xb = x[k0 + 1];  // k0 + 1 <= 576
+                const uint32_t xm = x[(k0 + 397 >= 624) ? k0 + 397 - 624 : k0 + 397];
                 const uint32_t y = (xa & 0x80000000u) | (xb & 0x7fffffffu);
-                nw = xm ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+                n0 = xm ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
             }
-            __syncthreads();  // single wave: orders the chunk's reads before its writes
-            if (k < 624) x[k] = nw;
-            __syncthreads();
+            if (k1 < 624) {
+                const uint32_t xa = x[k1];
+                const uint32_t xb = x[(k1 + 1 == 624) ? 0 : k1 + 1];  // k1 = 623 reads the NEW x[0] (step 0)
+                const uint32_t xm = x[(k1 + 397 >= 624) ? k1 + 397 - 624 : k1 + 397];
+                const uint32_t y = (xa & 0x80000000u) | (xb & 0x7fffffffu);
+                n1 = xm ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            }
+            // single wave, LDS executes a wave's operations in order: only the COMPILER must be kept
+            // from moving the step's writes above its reads (other lanes' elements)
+            __builtin_amdgcn_wave_barrier();
+            x[k0] = n0;
+            if (k1 < 624) x[k1] = n1;
+            __builtin_amdgcn_wave_barrier();
         }
+#pragma unroll
         for (int q = lane; q < 312; q += 64) {
             if (pos + q < end) {
                 const double wa = (double)mt_temper(x[2 * q]);
@@ -882,7 +926,7 @@ __global__ __launch_bounds__(64) void mt_jitter_kernel(const uint32_t* __restric
                 out[pos + q] = ret - 0.5;
             }
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
