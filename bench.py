@@ -229,10 +229,11 @@ def main():
                        "parallelism": f"frame-sharded x{world}, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "rtk::render_kernel", "kernel_ms": kms, "bytes_per_ray": bray,
+                         "kernel": "rtk::render_packet_kernel", "kernel_ms": kms, "bytes_per_ray": bray,
                          "rays_per_launch": rays_per_frame, "nodes_per_ray": cs["nodes_visited"] / cs["rays"],
                          "tris_per_ray": cs["tris_tested"] / cs["rays"], "hit_rate": cs["rays_hit"] / cs["rays"],
-                         "kernel_only_mrays_s": rays_per_frame / (kms * 1e-3) / 1e6},
+                         "kernel_only_mrays_s": rays_per_frame / (kms * 1e-3) / 1e6,
+                         "wave_node_fetches_per_ray": cs["wave_node_fetches"] / cs["rays"]},
             "cpu_baseline": cpu,
             "aux": {"jitter_kernel_ms": jms, "host_jump_ms_per_frame": hjm, "host_bvh_build_s": build_s,
                     "upload_s": upload_s, "stack_need": int(host.info.stack_need)},

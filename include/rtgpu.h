@@ -157,6 +157,7 @@ typedef struct {
     uint64_t nodes_visited; /* RT_FLAG_COUNTERS: TLAS+BLAS nodes slab-tested */
     uint64_t tris_tested;   /* RT_FLAG_COUNTERS */
     uint64_t rays_hit;      /* RT_FLAG_COUNTERS */
+    uint64_t wave_node_fetches; /* RT_FLAG_COUNTERS: node records fetched per wave, summed (packet kernel) */
 } rt_stats;
 int rt_last_stats(const rt_ctx *ctx, rt_stats *out);
 int rt_sync(rt_ctx *ctx);

@@ -94,6 +94,8 @@ struct rt_ctx {
     // camera-relative copies for the packet kernel (rebuilt per render by the prep kernels)
     DevBuf<rt::DevNode> cam_nodes, cam_tlas;
     DevBuf<rtk::CamTri> cam_tris;
+    DevBuf<rtk::FrameParams> frame_params;
+    rtk::FrameParams h_frame_params;  // host copy kept alive for the async upload
     size_t n_nodes = 0, n_tlas = 0;
     int32_t stack_need = 1;
     int64_t n_tris = 0;
@@ -442,6 +444,7 @@ void rt_destroy(rt_ctx* c) {
     c->cam_nodes.release();
     c->cam_tlas.release();
     c->cam_tris.release();
+    c->frame_params.release();
     c->d_states.release();
     c->jitter.release();
     for (auto& sl : c->slot) {
@@ -671,11 +674,15 @@ int rt_render(rt_ctx* c, const rt_render_params* p) {
         a.sc.leaf_ext = c->leaf_ext.p;
         a.sc.tris = c->cam_tris.p;
         a.sc.colors = c->colors.p;
+        if ((rc = c->frame_params.ensure(1))) return rc;
         for (int i = 0; i < 3; ++i) {
-            a.cam[i] = p->camera_center[i];
-            a.p00[i] = p->pixel_00_center[i];
+            c->h_frame_params.cam[i] = p->camera_center[i];
+            c->h_frame_params.p00[i] = p->pixel_00_center[i];
         }
-        for (int i = 0; i < 6; ++i) a.sp[i] = p->pixel_spacing[i];
+        for (int i = 0; i < 6; ++i) c->h_frame_params.sp[i] = p->pixel_spacing[i];
+        HIP_TRY(hipMemcpyAsync(c->frame_params.p, &c->h_frame_params, sizeof(rtk::FrameParams), hipMemcpyHostToDevice,
+                               c->stream));
+        a.fp = c->frame_params.p;
         a.W = W;
         a.spp = spp;
         a.row0 = p->row_begin;
@@ -786,6 +793,7 @@ int rt_last_stats(const rt_ctx* cc, rt_stats* out) {
             c->stats.nodes_visited = h[0];
             c->stats.tris_tested = h[1];
             c->stats.rays_hit = h[2];
+            c->stats.wave_node_fetches = h[3];
         }
         c->timing_pending = false;
     }

@@ -507,6 +507,7 @@ __device__ __forceinline__ unsigned long long slab_rel(const SBox& b, const doub
 // stack entries carry the mask of lanes that passed the pushed node's slab test.
 struct WaveCounters {
     unsigned long long nodes, tris;  // wave-uniform sums over participating lanes
+    unsigned long long steps;        // node records fetched by the wave (the packet's own work)
 };
 
 template <bool FAST, bool COUNT>
@@ -624,7 +625,10 @@ __device__ __forceinline__ void trace_packet(const PacketScene& sc, const unsign
             // load of the taken child's descriptor behind the branch: a second latency per step)
             asm volatile("" : "+s"(dl), "+s"(dr));
         }
-        if (COUNT) wc.nodes += 2u * (unsigned)__builtin_popcountll(inm);
+        if (COUNT) {
+            wc.nodes += 2u * (unsigned)__builtin_popcountll(inm);
+            wc.steps += 2u;
+        }
         const unsigned long long ml = slab_rel<FAST>(bl, ix, iy, iz) & inm;
         const unsigned long long mr = slab_rel<FAST>(br, ix, iy, iz) & inm;
         if (ml != 0ull) {
@@ -640,9 +644,15 @@ __device__ __forceinline__ void trace_packet(const PacketScene& sc, const unsign
     }
 }
 
+// Per-frame camera block, read with scalar loads where it is needed (ray generation) instead of
+// living in SGPRs across the traversal loop.
+struct FrameParams {
+    double cam[3], p00[3], sp[6];
+};
+
 struct PacketArgs {
     PacketScene sc;
-    double cam[3], p00[3], sp[6];
+    const FrameParams* fp;
     int32_t W, spp;
     int32_t row0, rows;
     int32_t tile_log2;
@@ -657,37 +667,51 @@ struct PacketArgs {
 
 constexpr int PACKET_STACK = 128;  // entries of the per-wave LDS stack ({descriptor, lane mask}, 16 B each)
 
+// One workgroup = one square pixel tile, one wave = one quarter of the tile's pixels (a compact
+// quadrant in Morton order).  A wave walks its own pixels' samples 64 at a time and owns its part
+// of the accumulation, so waves never wait for each other: there is no workgroup barrier.
+// Rays are ordered pixel-major with the samples of a pixel innermost: at spp >= 64 the 64 lanes
+// of a wave are samples of ONE pixel, otherwise a compact block of neighbouring pixels.
+// Sample colours go through the wave's LDS slice and are added per pixel in sample order
+// k = 0..spp-1 by one lane per (pixel, channel): bit-identical to the reference's serial sum
+// (cpp/rtrender.cpp:51-60) whatever the tiling or GPU count.
 template <bool COUNT>
-__global__ __launch_bounds__(NT) void render_packet_kernel(const PacketArgs a) {
+__global__ __launch_bounds__(NT, 8) void render_packet_kernel(const PacketArgs a) {
     __shared__ uint4 s_wstk[NT / 64][PACKET_STACK];
-    __shared__ double s_col[3][NT];
-    __shared__ double s_acc[3][NT];
+    __shared__ double s_col[NT / 64][3][64];
+    __shared__ double s_acc[NT / 64][3][64];
 
     const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = tid >> 6;
     int tile = blockIdx.x;
     {
         const int nb = a.n_tiles, per = nb >> 3, main = per << 3;
         if ((int)blockIdx.x < main) tile = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
     }
     const int ts = 1 << a.tile_log2;
-    const int npix_tile = ts * ts;
+    const int npix_w = (ts * ts) >> 2;  // pixels per wave: 16 (8x8 tile) or 64 (16x16 tile)
+    const int m0 = wv * npix_w;         // first Morton index of this wave's quadrant
     const int tx0 = (tile % a.tiles_x) << a.tile_log2;
     const int ty0 = (tile / a.tiles_x) << a.tile_log2;
     const int spp = a.spp;
-    const int n_rays = npix_tile * spp;
-    uint4* wstk = s_wstk[tid >> 6];
+    const int n_rays = npix_w * spp;
+    uint4* wstk = s_wstk[wv];
+    double(*wcol)[64] = s_col[wv];
+    double(*wacc)[64] = s_acc[wv];
 
-    s_acc[0][tid] = 0.0;
-    s_acc[1][tid] = 0.0;
-    s_acc[2][tid] = 0.0;
+    wacc[0][lane] = 0.0;
+    wacc[1][lane] = 0.0;
+    wacc[2][lane] = 0.0;
 
-    unsigned long long w_nodes = 0, w_tris = 0;  // lane 0 of each wave carries the wave's sums
+    unsigned long long w_nodes = 0, w_tris = 0, w_steps = 0;  // lane 0 of each wave carries the wave's sums
     uint32_t n_hits = 0;
 
-    for (int base = 0; base < n_rays; base += NT) {
-        const int rr = base + tid;
-        const int m = rr / spp;
-        const int k = rr - m * spp;
+    for (int base = 0; base < n_rays; base += 64) {
+        const int rr = base + lane;
+        const int ml = rr / spp;
+        const int k = rr - ml * spp;
+        const int m = m0 + ml;
         const int px = tx0 + (int)compact1by1((uint32_t)m);
         const int py = ty0 + (int)compact1by1((uint32_t)m >> 1);
         const bool active = (rr < n_rays) && (px < a.W) && (py < a.rows);
@@ -695,17 +719,19 @@ __global__ __launch_bounds__(NT) void render_packet_kernel(const PacketArgs a) {
         const size_t sidx = active ? ((size_t)py * a.W + px) * (size_t)spp + k : 0;
         double dx = 0.0, dy = 0.0, dz = -1.0;
         if (active) {
+            cdptr fp = (cdptr)(const void*)a.fp;  // cam[0..2] p00[3..5] sp[6..11]
             const d2 jit = reinterpret_cast<const d2*>(a.jitter)[sidx];
+            // cpp/rtrender.cpp:53-58
             const double s0 = (double)px + jit.x;
             const double s1 = (double)(py + a.row0) + jit.y;
-            const double ddx = ((a.p00[0] + s0 * a.sp[0]) + s1 * a.sp[3]) - a.cam[0];
-            const double ddy = ((a.p00[1] + s0 * a.sp[1]) + s1 * a.sp[4]) - a.cam[1];
-            const double ddz = ((a.p00[2] + s0 * a.sp[2]) + s1 * a.sp[5]) - a.cam[2];
+            const double ddx = ((fp[3] + s0 * fp[6]) + s1 * fp[9]) - fp[0];
+            const double ddy = ((fp[4] + s0 * fp[7]) + s1 * fp[10]) - fp[1];
+            const double ddz = ((fp[5] + s0 * fp[8]) + s1 * fp[11]) - fp[2];
             const double z = (ddx * ddx + ddy * ddy) + ddz * ddz;
             dx = ddx;
             dy = ddy;
             dz = ddz;
-            if (z > 0.0) {
+            if (z > 0.0) {  // Eigen normalized(): v / sqrt(squaredNorm) when squaredNorm > 0
                 const double nz = __builtin_sqrt(z);
                 dx = ddx / nz;
                 dy = ddy / nz;
@@ -721,17 +747,19 @@ __global__ __launch_bounds__(NT) void render_packet_kernel(const PacketArgs a) {
         const bool risky = active && (__builtin_isinf(ix) || __builtin_isinf(iy) || __builtin_isinf(iz));
         const unsigned long long amask = __builtin_amdgcn_ballot_w64(active);
         if (amask != 0ull) {
-            WaveCounters wc = {0ull, 0ull};
+            WaveCounters wc = {0ull, 0ull, 0ull};
             if (__builtin_amdgcn_ballot_w64(risky) != 0ull)
                 trace_packet<false, COUNT>(a.sc, amask, dx, dy, dz, ix, iy, iz, wstk, h, wc);
             else
                 trace_packet<true, COUNT>(a.sc, amask, dx, dy, dz, ix, iy, iz, wstk, h, wc);
-            if (COUNT && (tid & 63) == 0) {
+            if (COUNT && lane == 0) {
                 w_nodes += wc.nodes;
                 w_tris += wc.tris;
+                w_steps += wc.steps;
             }
         }
         if (active) {
+            // return_ray_color, cpp/rtrender.cpp:21-32
             if (h.t != __builtin_inf()) {
                 const double* fc = a.sc.colors + (size_t)h.prim * 3;
                 const double w = (1.0 - h.u) - h.v;
@@ -750,33 +778,36 @@ __global__ __launch_bounds__(NT) void render_packet_kernel(const PacketArgs a) {
             if (a.hit_prim) a.hit_prim[sidx] = h.prim;
             if (a.hit_t) a.hit_t[sidx] = h.t;
         }
-        s_col[0][tid] = c0;
-        s_col[1][tid] = c1;
-        s_col[2][tid] = c2;
-        __syncthreads();
+        wcol[0][lane] = c0;
+        wcol[1][lane] = c1;
+        wcol[2][lane] = c2;
+        // one wave, in-order LDS: only the compiler needs the fence
+        __builtin_amdgcn_wave_barrier();
         {
-            const int end = min(base + NT, n_rays);
+            const int end = min(base + 64, n_rays);
             const int m_first = base / spp;
             const int m_last = (end - 1) / spp;
             const int work = (m_last - m_first + 1) * 3;
-            for (int q = tid; q < work; q += NT) {
+            for (int q = lane; q < work; q += 64) {
                 const int pm = m_first + q / 3;
                 const int c = q - (q / 3) * 3;
                 const int lo = max(pm * spp, base) - base;
                 const int hi = min((pm + 1) * spp, end) - base;
-                double acc = s_acc[c][pm];
-                for (int s = lo; s < hi; ++s) acc += s_col[c][s];
-                s_acc[c][pm] = acc;
+                double acc = wacc[c][pm];
+                for (int s = lo; s < hi; ++s) acc += wcol[c][s];
+                wacc[c][pm] = acc;
             }
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
     }
 
-    if (tid < npix_tile) {
-        const int px = tx0 + (int)compact1by1((uint32_t)tid);
-        const int py = ty0 + (int)compact1by1((uint32_t)tid >> 1);
+    if (lane < npix_w) {
+        const int m = m0 + lane;
+        const int px = tx0 + (int)compact1by1((uint32_t)m);
+        const int py = ty0 + (int)compact1by1((uint32_t)m >> 1);
         if (px < a.W && py < a.rows) {
-            const double gray = (0.2126 * s_acc[0][tid] + 0.7152 * s_acc[1][tid]) + 0.0722 * s_acc[2][tid];
+            // cpp/rtrender.cpp:61-65
+            const double gray = (0.2126 * wacc[0][lane] + 0.7152 * wacc[1][lane]) + 0.0722 * wacc[2][lane];
             const double inten = gray / (double)spp;
             const int gb = (int)(inten * 255.99);
             const size_t pidx = (size_t)py * a.W + px;
@@ -795,10 +826,11 @@ __global__ __launch_bounds__(NT) void render_packet_kernel(const PacketArgs a) {
             v1 += __shfl_down(v1, off, 64);
             v2 += __shfl_down(v2, off, 64);
         }
-        if ((tid & 63) == 0 && a.counters) {
+        if (lane == 0 && a.counters) {
             atomicAdd(&a.counters[0], v0);
             atomicAdd(&a.counters[1], v1);
             atomicAdd(&a.counters[2], v2);
+            atomicAdd(&a.counters[3], w_steps);
         }
     }
 }
