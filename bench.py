@@ -199,6 +199,17 @@ def main():
                 traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        # host hand-over cost (PCIe), never part of `value`
+        frame(0)
+        ctx.sync()
+        t1 = time.perf_counter()
+        ctx.download(hit_ids=False)
+        dl_frame_ms = (time.perf_counter() - t1) * 1e3
+        dl_ids_ms = None
+        if want_ids:
+            t1 = time.perf_counter()
+            ctx.download(intensity=False, rgb=False, hit_ids=True)
+            dl_ids_ms = (time.perf_counter() - t1) * 1e3
         cpu = None
         if args.cpu_rays > 0:
             frame(0)
@@ -236,7 +247,9 @@ def main():
                          "wave_node_fetches_per_ray": cs["wave_node_fetches"] / cs["rays"]},
             "cpu_baseline": cpu,
             "aux": {"jitter_kernel_ms": jms, "host_jump_ms_per_frame": hjm, "host_bvh_build_s": build_s,
-                    "upload_s": upload_s, "stack_need": int(host.info.stack_need)},
+                    "upload_s": upload_s, "stack_need": int(host.info.stack_need),
+                    "download_frame_ms": dl_frame_ms, "download_hit_ids_ms": dl_ids_ms,
+                    "kernel_ms_timed_step": kernel_ms[-1] if kernel_ms else None},
         }
     if dist is not None:
         dist.barrier()

@@ -192,6 +192,13 @@ int rt_render_scene(int image_height, int image_width, int number_of_samples, co
                     const double *camera_centers, const double *pixel_00_centers,
                     const double *pixel_spacings, int device, int rank, int world);
 
+/* Host-only: the frame schedule rt_render_scene uses.  For rank `rank` of `world` it lists the frames
+ * f = t*n_cameras + c it renders (f % world == rank) and the position of each in the global RNG
+ * stream (stream_base + f*frame_words).  Returns the number of frames written (<= capacity), or a
+ * negative error.  frames/positions may be NULL to query the count only. */
+int64_t rt_shard_frames(int timestep_count, int n_cameras, int rank, int world, uint64_t stream_base,
+                        uint64_t frame_words, int64_t capacity, int64_t *frames, uint64_t *positions);
+
 /* P6 writer: "P6\nW H\n255\n" + payload (rtrender.cpp:69-81). Prints the
  * reference's messages ("Failed to open the output file." / " Done."). */
 int rt_write_ppm(const char *path, int width, int height, const uint8_t *rgb);

@@ -208,6 +208,17 @@ def mt19937_stream_states(base, stride, n, seed=5489):
     return out
 
 
+def shard_frames(timestep_count, n_cameras, rank, world, stream_base=0, frame_words=0):
+    """Frames (t*n_cameras + c) rank `rank` of `world` renders, and their RNG stream positions."""
+    n = lib.rt_shard_frames(timestep_count, n_cameras, rank, world, stream_base, frame_words, 0, None, None)
+    if n < 0:
+        raise L.RtError(lib.rt_last_error().decode())
+    frames = np.empty(max(n, 1), np.int64)
+    pos = np.empty(max(n, 1), np.uint64)
+    lib.rt_shard_frames(timestep_count, n_cameras, rank, world, stream_base, frame_words, n, L.ptr(frames), L.ptr(pos))
+    return frames[:n], pos[:n]
+
+
 def write_ppm(path, rgb):
     rgb = np.ascontiguousarray(rgb, np.uint8)
     h, w = rgb.shape[:2]

@@ -889,6 +889,20 @@ int rt_write_ppm(const char* path, int width, int height, const uint8_t* rgb) {
     return RT_OK;
 }
 
+int64_t rt_shard_frames(int timestep_count, int n_cameras, int rank, int world, uint64_t stream_base,
+                        uint64_t frame_words, int64_t capacity, int64_t* frames, uint64_t* positions) {
+    if (timestep_count < 0 || n_cameras < 0 || world < 1 || rank < 0 || rank >= world)
+        return fail(RT_E_INVALID, "rt_shard_frames: bad counts");
+    const int64_t total = int64_t(timestep_count) * n_cameras;
+    int64_t n = 0;
+    for (int64_t f = rank; f < total; f += world) {
+        if (frames && n < capacity) frames[n] = f;
+        if (positions && n < capacity) positions[n] = stream_base + uint64_t(f) * frame_words;
+        ++n;
+    }
+    return n;
+}
+
 int rt_render_scene(int image_height, int image_width, int number_of_samples, const char* output_directory,
                     int timestep_count, int n_meshes, const double* const* coords, const double* const* colors,
                     const int64_t* elem_counts, int n_cameras, const double* camera_centers,
@@ -911,43 +925,44 @@ int rt_render_scene(int image_height, int image_width, int number_of_samples, co
     const uint64_t base = rt_rng_tell(c);
     std::vector<uint8_t> rgb(size_t(image_height) * size_t(image_width) * 3);
     int rc = RT_OK;
-    for (int t = 0; t < timestep_count; ++t) {
-        bool mine = false;
-        for (int cam = 0; cam < n_cameras; ++cam)
-            if ((int64_t(t) * n_cameras + cam) % world == rank) mine = true;
-        if (!mine) continue;
-        rt_scene* sc = rt_scene_build(n_meshes, coords, colors, elem_counts, t, 0);
-        if (!sc) return RT_E_INVALID;
-        for (int64_t k = 0; k < sc->s->midpoint_fallbacks; ++k)
-            std::printf("SAH splitting failed. Trying midpoint instead.\n");  // cpp/rtbvh.cpp:128
-        rc = rt_upload_scene(c, sc);
-        rt_scene_free(sc);
-        if (rc) return rc;
-        for (int cam = 0; cam < n_cameras; ++cam) {
-            const int64_t frame = int64_t(t) * n_cameras + cam;
-            if (frame % world != rank) continue;
-            if ((rc = rt_rng_seek(c, base + uint64_t(frame) * frame_words))) return rc;
-            std::printf("Rendering frame %d/%d\n", t + 1, timestep_count);  // cpp/rtmain.cpp:61
-            std::fflush(stdout);
-            rt_render_params p;
-            std::memset(&p, 0, sizeof(p));
-            std::memcpy(p.camera_center, camera_centers + 3 * cam, 3 * sizeof(double));
-            std::memcpy(p.pixel_00_center, pixel_00_centers + 3 * cam, 3 * sizeof(double));
-            std::memcpy(p.pixel_spacing, pixel_spacings + 6 * cam, 6 * sizeof(double));
-            p.image_height = image_height;
-            p.image_width = image_width;
-            p.samples = number_of_samples;
-            p.row_begin = 0;
-            p.row_end = image_height;
-            p.sampler = RT_SAMPLER_MT19937;
-            if ((rc = rt_render(c, &p))) return rc;
-            if ((rc = rt_download(c, nullptr, rgb.data(), nullptr, nullptr))) return rc;
-            // cpp/rtmain.cpp:58-60: rtimage_<timestep>_cam<camera>.ppm, zero-based
-            std::string path = std::string(output_directory) + "/rtimage_" + std::to_string(t) + "_cam" +
-                               std::to_string(cam) + ".ppm";
-            // like the reference, an unopenable file is reported and the job goes on
-            (void)rt_write_ppm(path.c_str(), image_width, image_height, rgb.data());
+    const int64_t n_mine = rt_shard_frames(timestep_count, n_cameras, rank, world, base, frame_words, 0, nullptr, nullptr);
+    std::vector<int64_t> my_frames((size_t)std::max<int64_t>(n_mine, 1));
+    std::vector<uint64_t> my_pos((size_t)std::max<int64_t>(n_mine, 1));
+    rt_shard_frames(timestep_count, n_cameras, rank, world, base, frame_words, n_mine, my_frames.data(), my_pos.data());
+    int built_t = -1;
+    for (int64_t q = 0; q < n_mine; ++q) {
+        const int t = (int)(my_frames[q] / n_cameras), cam = (int)(my_frames[q] % n_cameras);
+        if (t != built_t) {  // frames arrive timestep-major: one build per timestep this rank touches
+            rt_scene* sc = rt_scene_build(n_meshes, coords, colors, elem_counts, t, 0);
+            if (!sc) return RT_E_INVALID;
+            for (int64_t k = 0; k < sc->s->midpoint_fallbacks; ++k)
+                std::printf("SAH splitting failed. Trying midpoint instead.\n");  // cpp/rtbvh.cpp:128
+            rc = rt_upload_scene(c, sc);
+            rt_scene_free(sc);
+            if (rc) return rc;
+            built_t = t;
         }
+        if ((rc = rt_rng_seek(c, my_pos[q]))) return rc;
+        std::printf("Rendering frame %d/%d\n", t + 1, timestep_count);  // cpp/rtmain.cpp:61
+        std::fflush(stdout);
+        rt_render_params p;
+        std::memset(&p, 0, sizeof(p));
+        std::memcpy(p.camera_center, camera_centers + 3 * cam, 3 * sizeof(double));
+        std::memcpy(p.pixel_00_center, pixel_00_centers + 3 * cam, 3 * sizeof(double));
+        std::memcpy(p.pixel_spacing, pixel_spacings + 6 * cam, 6 * sizeof(double));
+        p.image_height = image_height;
+        p.image_width = image_width;
+        p.samples = number_of_samples;
+        p.row_begin = 0;
+        p.row_end = image_height;
+        p.sampler = RT_SAMPLER_MT19937;
+        if ((rc = rt_render(c, &p))) return rc;
+        if ((rc = rt_download(c, nullptr, rgb.data(), nullptr, nullptr))) return rc;
+        // cpp/rtmain.cpp:58-60: rtimage_<timestep>_cam<camera>.ppm, zero-based
+        std::string path = std::string(output_directory) + "/rtimage_" + std::to_string(t) + "_cam" +
+                           std::to_string(cam) + ".ppm";
+        // like the reference, an unopenable file is reported and the job goes on
+        (void)rt_write_ppm(path.c_str(), image_width, image_height, rgb.data());
     }
     // every rank leaves the global stream where the unsharded job would have left it
     return rt_rng_seek(c, base + uint64_t(timestep_count) * uint64_t(n_cameras) * frame_words);

@@ -287,3 +287,40 @@ def test_render_scene_driver_files_and_sharding(ctx, tmp_path):
             want = osc.render(*cam, H, W, spp, rng=rng, want_hits=False)
             data = (out / f"rtimage_{t}_cam{ci}.ppm").read_bytes()
             assert data == hdr + want["rgb"].tobytes(), (t, ci)
+
+
+_SHARD_SCRIPT = r'''
+import sys, os
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+import raytracer_amd as ra
+from raytracer_amd import meshgen
+out, rank, world = sys.argv[2], sys.argv[3], sys.argv[4]
+os.environ["RT_SHARD_FRAMES"] = "1"; os.environ["RANK"] = rank; os.environ["WORLD_SIZE"] = world
+os.environ["LOCAL_RANK"] = "0"
+c, k = meshgen.plate(12, T=3, sway=0.2)
+sc = ra.Scene(); sc.add_mesh(c, None, None, k, 3)
+for cam in (meshgen.camera_arrays(20, 12), meshgen.camera_arrays(20, 12, center=(0.4, 0.1, 0.2), fov=70)):
+    sc.add_camera(*cam)
+ra.render_scene(12, 20, sc, 3, out)
+'''
+
+
+def test_frame_sharding_gives_identical_files(tmp_path):
+    """Each rank is its own process (as under torchrun); world=2 ranks together must write exactly the files a
+    single process writes, byte for byte (every rank seeks the global RNG stream to its frames)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "shard.py"
+    script.write_text(_SHARD_SCRIPT)
+    single, split = tmp_path / "single", tmp_path / "split"
+    single.mkdir()
+    split.mkdir()
+    subprocess.check_call([sys.executable, str(script), root, str(single), "0", "1"], timeout=300)
+    for r in ("0", "1"):
+        subprocess.check_call([sys.executable, str(script), root, str(split), r, "2"], timeout=300)
+    names = sorted(os.listdir(single))
+    assert len(names) == 6 and names == sorted(os.listdir(split))
+    for n in names:
+        assert (single / n).read_bytes() == (split / n).read_bytes(), n

@@ -1,0 +1,81 @@
+"""N>1 path on CPU: two gloo ranks ask the product's frame scheduler (rt_shard_frames, the function
+rt_render_scene itself uses) for their shards; together they must cover every frame exactly once, in the
+reference's (timestep outer, camera inner) numbering, each at the right position of the never-reseeded RNG
+stream -- and the generator state each rank would start from must equal sequential generation."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, T, C, frame_words, out):
+    sys.path.insert(0, os.path.dirname(HERE))
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import orc
+    import raytracer_amd as ra
+    frames, pos = ra.shard_frames(T, C, rank, world, stream_base=0, frame_words=frame_words)
+    # every frame's start state from the jump-ahead == sequential generation (checked on the first two)
+    ok = 1
+    for f, p in list(zip(frames, pos))[:2]:
+        st = ra.mt19937_state_at(int(p))
+        g = orc.Rng()
+        g.set_state(st)
+        h = orc.Rng()
+        h.discard(int(p))
+        ok &= int(np.array_equal(g.u32(64), h.u32(64)))
+    mine = torch.full((T * C,), -1, dtype=torch.int64)
+    mine[: len(frames)] = torch.from_numpy(frames.astype(np.int64))
+    gathered = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    flag = torch.tensor([ok])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        allf = torch.cat(gathered)
+        allf = allf[allf >= 0]
+        out.put((sorted(allf.tolist()), int(flag.item()), [int(x) for x in pos]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_cover_all_frames_once():
+    world, T, C = 2, 5, 3
+    frame_words = 18 * 30 * 2 * 4
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, T, C, frame_words, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    frames, ok, pos0 = out.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert frames == list(range(T * C))
+    assert ok == 1
+    assert pos0 == [f * frame_words for f in range(0, T * C, world)]
+
+
+def test_schedule_edge_cases():
+    sys.path.insert(0, os.path.dirname(HERE))
+    import raytracer_amd as ra
+    f, p = ra.shard_frames(0, 2, 0, 1)
+    assert len(f) == 0
+    f, p = ra.shard_frames(3, 1, 3, 4, stream_base=100, frame_words=7)
+    assert len(f) == 0
+    f, p = ra.shard_frames(3, 2, 1, 4, stream_base=100, frame_words=7)
+    assert f.tolist() == [1, 5] and p.tolist() == [107, 135]
