@@ -97,6 +97,7 @@ struct rt_ctx {
     DevBuf<rtk::FrameParams> frame_params;
     rtk::FrameParams h_frame_params;  // host copy kept alive for the async upload
     size_t n_nodes = 0, n_tlas = 0;
+    double max_abs_coord = 0.0;  // largest |coordinate| of the uploaded scene (NaN/inf -> inf)
     int32_t stack_need = 1;
     int64_t n_tris = 0;
     // sampler
@@ -515,6 +516,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* scene) {
     // scene may be freed by the caller right away, so wait for them here.
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->stack_need = s.stack_need;
+    c->max_abs_coord = s.max_abs_coord;
     c->n_tris = (int64_t)s.prim_mesh.size();
     c->have_scene = true;
     return RT_OK;
@@ -696,6 +698,7 @@ int rt_render(rt_ctx* c, const rt_render_params* p) {
         a.hit_prim = (p->flags & RT_FLAG_HIT_IDS) ? c->hit_prim.p : nullptr;
         a.hit_t = (p->flags & RT_FLAG_HIT_T) ? c->hit_t.p : nullptr;
         a.counters = count ? c->counters.p : nullptr;
+        a.fast_ok = (c->max_abs_coord + std::fabs(ox) + std::fabs(oy) + std::fabs(oz)) < 1e100 ? 1 : 0;
         HIP_TRY(hipEventRecord(c->ev[0], c->stream));
         if (count)
             hipLaunchKernelGGL(rtk::render_packet_kernel<true>, dim3((unsigned)n_tiles), dim3(rtk::NT), 0, c->stream, a);

@@ -429,6 +429,14 @@ Scene* build_scene(int n_meshes, const double* const* coords, const double* cons
         }
     }
     sc->stack_need = std::max(1, tneed[0]) + 1;
+    {
+        double m = 0.0;
+        for (double v : sc->tris) {
+            const double a = std::fabs(v);
+            if (!(a <= m)) m = (a == a) ? a : kInf;  // NaN -> inf
+        }
+        sc->max_abs_coord = m;
+    }
 
     sc->build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     return sc.release();

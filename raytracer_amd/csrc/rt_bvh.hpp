@@ -66,6 +66,7 @@ struct Scene {
     std::vector<double> colors;       // n_tris * 3, same order
     std::vector<int32_t> prim_mesh, prim_elem;  // prim id -> original ids
     int32_t stack_need = 1;
+    double max_abs_coord = 0.0;  // max |vertex coordinate|; +inf if any coordinate is NaN/inf
     int32_t max_leaf_tris = 0;
     int64_t midpoint_fallbacks = 0;
     int64_t n_blas_nodes = 0;

@@ -499,8 +499,11 @@ __device__ __forceinline__ unsigned long long slab_rel(const SBox& b, const doub
     }
     // one ballot per comparison: each v_cmp writes its lane mask straight into an SGPR pair and the
     // masks are combined on the scalar unit
-    return __builtin_amdgcn_ballot_w64(tmin <= tmax) & __builtin_amdgcn_ballot_w64(tmax > 0.0) &
-           __builtin_amdgcn_ballot_w64(tmin < __builtin_inf());
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(tmin <= tmax) & __builtin_amdgcn_ballot_w64(tmax > 0.0);
+    // FAST is only selected when every |inverse direction| < 1e100 and every |box coordinate - camera|
+    // < 1e100 (host-checked): all six products are finite, so `tmin < inf` holds by construction.
+    if (FAST) return m;
+    return m & __builtin_amdgcn_ballot_w64(tmin < __builtin_inf());
 }
 
 // The set of lanes taking part in the current node is a wave-uniform 64-bit mask (SGPR pair);
@@ -518,129 +521,132 @@ __device__ __forceinline__ void trace_packet(const PacketScene& sc, const unsign
     int sp = 0;
     uint32_t cur = rt::DESC_TLAS;
     unsigned long long inm = valid_mask;
-    bool have = true;
     for (;;) {
-        if (!have) {
-            if (sp == 0) break;
-            --sp;
-            const uint4 e = wstk[sp];
-            cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.x);
-            const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.y);
-            const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.z);
-            inm = ((unsigned long long)hi << 32) | lo;
-        }
-        have = false;
-        if (cur & rt::DESC_LEAF) {
-            uint32_t first = cur & rt::DESC_TRI_MASK;
-            uint32_t cnt = ((cur >> 28) & 7u) + 1u;
-            if (cnt == 8u) {
-                cuptr ext = (cuptr)(const void*)sc.leaf_ext;
-                const uint32_t e = first;
-                first = ext[2 * e];
-                cnt = ext[2 * e + 1];
+        // ---- descend through internal BLAS nodes (the hot loop) ----
+        bool alive = true;
+        while ((cur & (rt::DESC_LEAF | rt::DESC_TLAS | rt::DESC_ROOT)) == 0u) {
+            // both children in one 128-byte scalar fetch, tested unconditionally (lanes outside
+            // `inm` compute garbage that the mask discards)
+            SBox bl, br;
+            uint32_t dl, dr;
+            {
+                cdptr q = (cdptr)(const void*)(sc.nodes + cur);
+                bl.mnx = q[0];
+                bl.mny = q[1];
+                bl.mnz = q[2];
+                bl.mxx = q[3];
+                bl.mxy = q[4];
+                bl.mxz = q[5];
+                br.mnx = q[8];
+                br.mny = q[9];
+                br.mnz = q[10];
+                br.mxx = q[11];
+                br.mxy = q[12];
+                br.mxz = q[13];
+                cuptr m = (cuptr)(const void*)(sc.nodes + cur);
+                dl = m[15];
+                dr = m[31];
+                // keep both descriptors in the one batch of scalar loads (hipcc otherwise sinks the
+                // load of the taken child's descriptor behind the branch: a second latency per step)
+                asm volatile("" : "+s"(dl), "+s"(dr));
             }
-            if (COUNT) wc.tris += (unsigned long long)cnt * (unsigned)__builtin_popcountll(inm);
-            const bool in = __builtin_amdgcn_inverse_ballot_w64(inm);
-            for (uint32_t k = 0; k < cnt; ++k) {
-                cdptr tp = (cdptr)(const void*)(sc.tris + (size_t)(first + k));
-                const double e0x = tp[0], e0y = tp[1], e0z = tp[2];
-                const double e2x = tp[3], e2y = tp[4], e2z = tp[5];
-                const double tvx = tp[6], tvy = tp[7], tvz = tp[8];
-                const double qx = tp[9], qy = tp[10], qz = tp[11];
-                const double tnum = tp[12];
-                // rtrayintersection.cpp:79-106, with the ray-independent parts precomputed
-                const double px = dy * e2z - dz * e2y;
-                const double py = dz * e2x - dx * e2z;
-                const double pz = dx * e2y - dy * e2x;
-                const double det = (e0x * px + e0y * py) + e0z * pz;
-                if (in && det > 1e-6) {
-                    const double inv = 1.0 / det;
-                    const double u = ((tvx * px + tvy * py) + tvz * pz) * inv;
-                    const double v = ((dx * qx + dy * qy) + dz * qz) * inv;
-                    const double t = tnum * inv;
-                    const bool ok = (u >= 0.0) && (u <= 1.0) && (v >= 0.0) && ((u + v) <= 1.0) && (t >= 0.0) &&
-                                    (t <= __builtin_inf());
-                    if (ok && t < h.t) {
-                        h.t = t;
-                        h.u = u;
-                        h.v = v;
-                        h.prim = (int32_t)(first + k);
+            if (COUNT) {
+                wc.nodes += 2u * (unsigned)__builtin_popcountll(inm);
+                wc.steps += 2u;
+            }
+            const unsigned long long ml = slab_rel<FAST>(bl, ix, iy, iz) & inm;
+            const unsigned long long mr = slab_rel<FAST>(br, ix, iy, iz) & inm;
+            if (ml != 0ull) {
+                if (mr != 0ull) wstk[sp++] = make_uint4(dr, (uint32_t)mr, (uint32_t)(mr >> 32), 0u);
+                cur = dl;
+                inm = ml;
+            } else if (mr != 0ull) {
+                cur = dr;
+                inm = mr;
+            } else {
+                alive = false;
+                break;
+            }
+        }
+        if (alive) {
+            if (cur & rt::DESC_LEAF) {
+                uint32_t first = cur & rt::DESC_TRI_MASK;
+                uint32_t cnt = ((cur >> 28) & 7u) + 1u;
+                if (cnt == 8u) {
+                    cuptr ext = (cuptr)(const void*)sc.leaf_ext;
+                    const uint32_t e = first;
+                    first = ext[2 * e];
+                    cnt = ext[2 * e + 1];
+                }
+                if (COUNT) wc.tris += (unsigned long long)cnt * (unsigned)__builtin_popcountll(inm);
+                const bool in = __builtin_amdgcn_inverse_ballot_w64(inm);
+                for (uint32_t k = 0; k < cnt; ++k) {
+                    cdptr tp = (cdptr)(const void*)(sc.tris + (size_t)(first + k));
+                    const double e0x = tp[0], e0y = tp[1], e0z = tp[2];
+                    const double e2x = tp[3], e2y = tp[4], e2z = tp[5];
+                    const double tvx = tp[6], tvy = tp[7], tvz = tp[8];
+                    const double qx = tp[9], qy = tp[10], qz = tp[11];
+                    const double tnum = tp[12];
+                    // rtrayintersection.cpp:79-106, with the ray-independent parts precomputed
+                    const double px = dy * e2z - dz * e2y;
+                    const double py = dz * e2x - dx * e2z;
+                    const double pz = dx * e2y - dy * e2x;
+                    const double det = (e0x * px + e0y * py) + e0z * pz;
+                    if (in && det > 1e-6) {
+                        const double inv = 1.0 / det;
+                        const double u = ((tvx * px + tvy * py) + tvz * pz) * inv;
+                        const double v = ((dx * qx + dy * qy) + dz * qz) * inv;
+                        const double t = tnum * inv;
+                        const bool ok = (u >= 0.0) && (u <= 1.0) && (v >= 0.0) && ((u + v) <= 1.0) && (t >= 0.0) &&
+                                        (t <= __builtin_inf());
+                        if (ok && t < h.t) {
+                            h.t = t;
+                            h.u = u;
+                            h.v = v;
+                            h.prim = (int32_t)(first + k);
+                        }
+                    }
+                }
+            } else {
+                SBox b;
+                int32_t left, count, first;
+                uint32_t desc;
+                if (cur & rt::DESC_TLAS) {
+                    sload_node(sc.tlas + (cur & 0x3FFFFFFFu), b, left, count, first, desc);
+                    if (COUNT) wc.nodes += (unsigned)__builtin_popcountll(inm);
+                    const unsigned long long hm = slab_rel<FAST>(b, ix, iy, iz) & inm;
+                    if (hm != 0ull) {
+                        const uint32_t lo = (uint32_t)hm, hi = (uint32_t)(hm >> 32);
+                        if (left < 0) {
+                            for (int32_t k = count - 1; k >= 0; --k)
+                                wstk[sp++] = make_uint4(rt::DESC_ROOT | (uint32_t)(first + k), lo, hi, 0u);
+                        } else {
+                            wstk[sp++] = make_uint4(rt::DESC_TLAS | (uint32_t)(left + 1), lo, hi, 0u);
+                            wstk[sp++] = make_uint4(rt::DESC_TLAS | (uint32_t)left, lo, hi, 0u);
+                        }
+                    }
+                } else {
+                    const RT_CONST int32_t* sr = (const RT_CONST int32_t*)(const void*)sc.slot_root;
+                    const int32_t root = sr[cur & 0x1FFFFFFFu];
+                    sload_node(sc.nodes + root, b, left, count, first, desc);
+                    if (COUNT) wc.nodes += (unsigned)__builtin_popcountll(inm);
+                    const unsigned long long hm = slab_rel<FAST>(b, ix, iy, iz) & inm;
+                    if (hm != 0ull) {
+                        cur = desc;
+                        inm = hm;
+                        continue;  // walk into this BLAS
                     }
                 }
             }
-            continue;
         }
-        if (cur & (rt::DESC_TLAS | rt::DESC_ROOT)) {
-            SBox b;
-            int32_t left, count, first;
-            uint32_t desc;
-            if (cur & rt::DESC_TLAS) {
-                sload_node(sc.tlas + (cur & 0x3FFFFFFFu), b, left, count, first, desc);
-                if (COUNT) wc.nodes += (unsigned)__builtin_popcountll(inm);
-                const unsigned long long hm = slab_rel<FAST>(b, ix, iy, iz) & inm;
-                if (hm == 0ull) continue;
-                const uint32_t lo = (uint32_t)hm, hi = (uint32_t)(hm >> 32);
-                if (left < 0) {
-                    for (int32_t k = count - 1; k >= 0; --k) wstk[sp++] = make_uint4(rt::DESC_ROOT | (uint32_t)(first + k), lo, hi, 0u);
-                } else {
-                    wstk[sp++] = make_uint4(rt::DESC_TLAS | (uint32_t)(left + 1), lo, hi, 0u);
-                    wstk[sp++] = make_uint4(rt::DESC_TLAS | (uint32_t)left, lo, hi, 0u);
-                }
-            } else {
-                const RT_CONST int32_t* sr = (const RT_CONST int32_t*)(const void*)sc.slot_root;
-                const int32_t root = sr[cur & 0x1FFFFFFFu];
-                sload_node(sc.nodes + root, b, left, count, first, desc);
-                if (COUNT) wc.nodes += (unsigned)__builtin_popcountll(inm);
-                const unsigned long long hm = slab_rel<FAST>(b, ix, iy, iz) & inm;
-                if (hm != 0ull) {
-                    cur = desc;
-                    inm = hm;
-                    have = true;
-                }
-            }
-            continue;
-        }
-        // internal BLAS node: both children in one 128-byte scalar fetch, tested unconditionally
-        // (lanes outside `inm` compute garbage that the mask discards)
-        SBox bl, br;
-        uint32_t dl, dr;
-        {
-            cdptr q = (cdptr)(const void*)(sc.nodes + cur);
-            bl.mnx = q[0];
-            bl.mny = q[1];
-            bl.mnz = q[2];
-            bl.mxx = q[3];
-            bl.mxy = q[4];
-            bl.mxz = q[5];
-            br.mnx = q[8];
-            br.mny = q[9];
-            br.mnz = q[10];
-            br.mxx = q[11];
-            br.mxy = q[12];
-            br.mxz = q[13];
-            cuptr m = (cuptr)(const void*)(sc.nodes + cur);
-            dl = m[15];
-            dr = m[31];
-            // keep both descriptors in the one batch of scalar loads (hipcc otherwise sinks the
-            // load of the taken child's descriptor behind the branch: a second latency per step)
-            asm volatile("" : "+s"(dl), "+s"(dr));
-        }
-        if (COUNT) {
-            wc.nodes += 2u * (unsigned)__builtin_popcountll(inm);
-            wc.steps += 2u;
-        }
-        const unsigned long long ml = slab_rel<FAST>(bl, ix, iy, iz) & inm;
-        const unsigned long long mr = slab_rel<FAST>(br, ix, iy, iz) & inm;
-        if (ml != 0ull) {
-            if (mr != 0ull) wstk[sp++] = make_uint4(dr, (uint32_t)mr, (uint32_t)(mr >> 32), 0u);
-            cur = dl;
-            inm = ml;
-            have = true;
-        } else if (mr != 0ull) {
-            cur = dr;
-            inm = mr;
-            have = true;
-        }
+        // ---- pop ----
+        if (sp == 0) break;
+        --sp;
+        const uint4 e = wstk[sp];
+        cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.x);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.y);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.z);
+        inm = ((unsigned long long)hi << 32) | lo;
     }
 }
 
@@ -663,6 +669,7 @@ struct PacketArgs {
     int32_t* hit_prim;
     double* hit_t;
     unsigned long long* counters;
+    int32_t fast_ok;  // host: every |node coordinate - camera| < 1e100
 };
 
 constexpr int PACKET_STACK = 128;  // entries of the per-wave LDS stack ({descriptor, lane mask}, 16 B each)
@@ -744,7 +751,9 @@ __global__ __launch_bounds__(NT, 8) void render_packet_kernel(const PacketArgs a
         h.u = 0.0;
         h.v = 0.0;
         h.prim = -1;
-        const bool risky = active && (__builtin_isinf(ix) || __builtin_isinf(iy) || __builtin_isinf(iz));
+        // FAST slab path needs every product (box - camera) * inverse direction finite and non-NaN
+        const bool tame = (__builtin_fabs(ix) < 1e100) && (__builtin_fabs(iy) < 1e100) && (__builtin_fabs(iz) < 1e100);
+        const bool risky = active && !(tame && a.fast_ok);
         const unsigned long long amask = __builtin_amdgcn_ballot_w64(active);
         if (amask != 0ull) {
             WaveCounters wc = {0ull, 0ull, 0ull};
@@ -794,7 +803,20 @@ __global__ __launch_bounds__(NT, 8) void render_packet_kernel(const PacketArgs a
                 const int lo = max(pm * spp, base) - base;
                 const int hi = min((pm + 1) * spp, end) - base;
                 double acc = wacc[c][pm];
-                for (int s = lo; s < hi; ++s) acc += wcol[c][s];
+                const double* src = &wcol[c][lo];
+                const int n = hi - lo;
+                int s2 = 0;
+                for (; s2 + 8 <= n; s2 += 8) {  // strictly in sample order; unrolled for LDS immediates
+                    acc += src[s2];
+                    acc += src[s2 + 1];
+                    acc += src[s2 + 2];
+                    acc += src[s2 + 3];
+                    acc += src[s2 + 4];
+                    acc += src[s2 + 5];
+                    acc += src[s2 + 6];
+                    acc += src[s2 + 7];
+                }
+                for (; s2 < n; ++s2) acc += src[s2];
                 wacc[c][pm] = acc;
             }
         }
