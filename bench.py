@@ -6,7 +6,7 @@ kernel), ray generation, TLAS/BLAS traversal, Moller-Trumbore, shading, in-order
 quantisation and per-sample hit-id output, with the flattened tree already resident in HBM (the host
 BVH build and the upload happen before the timed region and are reported separately).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4|plate1m|sphere]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4|plate1m|sphere|block]
 
 N > 1 is launched by torch.distributed.run, one rank per GPU; frames are sharded over ranks
 (frame f = step*N + rank, each at its own position of the reference's global RNG stream), with no
@@ -44,10 +44,23 @@ def workload(name):
         spp = 50
         label = "1,048,352-triangle deformed plate (1 BLAS), 2048x2048, 50 spp"
     elif name == "sphere":
-        c, k = meshgen.uv_sphere(50, 50, radius=1.0, center=(0.0, 0.0, -2.5))
-        coords, colors = [c], [k]
+        # BASELINE.json configs[1]: the reference's sphere_gmsh_vtk_test_2d_manyelems.vtk (data fixture),
+        # 1 camera, 50-sample anti-aliasing, 1 frame, at the reference's 400x225 (rttests.py:31-33)
+        from raytracer_amd import rtsimdataloader as loader
+        m = loader.vtk_mesh_to_rtmesh(os.path.join(ROOT, "tests", "golden", "sphere_gmsh_vtk_test_2d_manyelems.vtk"),
+                                      scale=2.0, world_position=np.array([0.0, 0.0, -2.2]))
+        m.set_surface(loader.SurfType.FIELD_COLOR, np.array([0.5, 0.5, 0.5]))
+        coords, colors = [m.node_coords_expanded_over_time], [m.face_colors_over_time]
         H, W, spp = 225, 400, 50
-        label = "configs[1]-shaped: 4,900-triangle sphere, 400x225, 50 spp"
+        label = "configs[1]: sphere_gmsh_vtk_test_2d_manyelems.vtk (4,992 triangles), 400x225, 50 spp"
+    elif name == "block":
+        # BASELINE.json configs[0]: simple_block.e, single mesh, single camera, 1 frame, no anti-aliasing
+        from raytracer_amd import rtsimdataloader as loader
+        m = loader.simdata_to_rtmesh(os.path.join(ROOT, "tests", "golden", "simple_block.e"), scale=100.0,
+                                     world_position=np.array([-0.5, -0.75, -2.0]))
+        coords, colors = [m.node_coords_expanded_over_time[4:5].copy()], [m.face_colors_over_time[4:5].copy()]
+        H, W, spp = 225, 400, 1
+        label = "configs[0]: simple_block.e surface (44 triangles), 400x225, 1 spp"
     else:
         raise SystemExit(f"unknown workload {name}")
     cam = meshgen.camera_arrays(W, H)

@@ -9,21 +9,12 @@ from enum import Enum
 
 import numpy as np
 
+from .rtsimdataloader import RTMesh, SurfType  # noqa: F401  (same import the reference has, rtscene.py:4)
+
 
 class RenderType(Enum):
     STATIC = 0
     DYNAMIC = 1
-
-
-@dataclass
-class RTMesh:
-    """Minimal stand-in for the reference's rtsimdataloader_new.RTMesh (only what Scene.add_rtmesh reads)."""
-    node_coords: np.ndarray = None
-    connectivity: np.ndarray = None
-    node_coords_expanded_over_time: np.ndarray = None
-    face_colors_over_time: np.ndarray = None
-    surface_type: str = None
-    timestep_count: int = 1
 
 
 @dataclass
@@ -61,7 +52,7 @@ class Scene:
             print("Please set surface type for mesh before adding it to the scene.")
             return
         self.coords_expanded.append(rtmesh.node_coords_expanded_over_time)
-        if str(rtmesh.surface_type) == "field_color":
+        if rtmesh.surface_type == SurfType.FIELD_COLOR:
             self.face_colors.append(rtmesh.face_colors_over_time)
         self.timestep_count = max(self.timestep_count, rtmesh.timestep_count)
 

@@ -324,3 +324,24 @@ def test_frame_sharding_gives_identical_files(tmp_path):
     assert len(names) == 6 and names == sorted(os.listdir(split))
     for n in names:
         assert (single / n).read_bytes() == (split / n).read_bytes(), n
+
+
+def test_reference_sample_files_render_like_the_oracle(ctx, tmp_path):
+    """BASELINE configs[0] and [1] from the reference's own data files (tests/golden/): simple_block.e over all
+    9 timesteps through the render_scene driver, and the VTK sphere at 50 spp."""
+    from raytracer_amd import rtsimdataloader as loader
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    # configs[1]
+    m = loader.vtk_mesh_to_rtmesh(os.path.join(gold, "sphere_gmsh_vtk_test_2d_manyelems.vtk"), scale=2.0,
+                                  world_position=np.array([0.0, 0.0, -2.2]))
+    m.set_surface(loader.SurfType.FIELD_COLOR, np.array([0.5, 0.5, 0.5]))
+    cam = meshgen.camera_arrays(80, 45)
+    got, want, _ = check_image(ctx, [m.node_coords_expanded_over_time], [m.face_colors_over_time], cam, 45, 80, 50)
+    assert 0.05 < (want["hit_elem"] >= 0).mean() < 0.9
+    # configs[0], every timestep
+    b = loader.simdata_to_rtmesh(os.path.join(gold, "simple_block.e"), scale=100.0,
+                                 world_position=np.array([-0.5, -0.75, -2.0]))
+    for t in (0, 4, 8):
+        got, want, _ = check_image(ctx, [b.node_coords_expanded_over_time], [b.face_colors_over_time],
+                                   meshgen.camera_arrays(100, 56), 56, 100, 1, timestep=t)
+        assert (want["hit_elem"] >= 0).mean() > 0.05

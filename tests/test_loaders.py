@@ -1,0 +1,67 @@
+"""Readers for the two sample files the reference ships (copied as data fixtures into tests/golden/).
+What the reference's own files pin: simple_block.e -> 44 surface triangles = (132, 3) expanded nodes
+(rttests.py:154,170), 9 timesteps; the VTK sphere -> 4992 type-5 cells.  Triangle ORDER vs pyvale/pyvista is
+unpinned (those libraries are not installable here).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+import raytracer_amd as ra
+from raytracer_amd import rtsimdataloader as L
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+BLOCK = os.path.join(GOLD, "simple_block.e")
+SPHERE = os.path.join(GOLD, "sphere_gmsh_vtk_test_2d_manyelems.vtk")
+
+
+def signed_volume(tris):
+    return np.einsum("ij,ij->i", tris[:, 0], np.cross(tris[:, 1], tris[:, 2])).sum() / 6
+
+
+def test_exodus_block_surface():
+    m = L.simdata_to_rtmesh(BLOCK, scale=100.0)
+    assert m.element_count == 44 and m.timestep_count == 9
+    assert m.node_coords_expanded_over_time.shape == (9, 44, 3, 3)
+    assert m.node_coords_expanded_over_time[0].reshape(-1, 3).shape == (132, 3)
+    assert m.face_colors_over_time.shape == (9, 44, 3)
+    assert m.node_coords_expanded_over_time.flags.c_contiguous and m.face_colors_over_time.flags.c_contiguous
+    # closed, outward-wound surface (10 x 15 x 5 mm block, scale 100 -> 1 x 1.5 x 0.5): positive volume
+    assert signed_volume(m.node_coords_expanded_over_time[0]) == pytest.approx(0.75, rel=1e-12)
+    # t = 0 is mid grey, later steps are min-max normalised x-displacement averaged per face
+    assert np.all(m.face_colors_over_time[0] == 0.5)
+    c = m.face_colors_over_time[3]
+    assert c.min() >= 0 and c.max() <= 1 and np.ptp(c) > 0.1 and np.all(c[:, 0] == c[:, 1])
+    # deformation moves the nodes
+    assert np.abs(m.node_coords_expanded_over_time[8] - m.node_coords_expanded_over_time[0]).max() > 0
+
+
+def test_exodus_into_scene_and_bvh():
+    sc = ra.Scene()
+    L.add_mesh_to_scene(sc, BLOCK, scale=1.0, world_position=np.array([0.0, 0.0, -3.0]))
+    assert sc.mesh_count == 1 and sc.timestep_count == 9
+    host = ra.HostScene(sc.coords_expanded, sc.face_colors, timestep=4)
+    assert host.info.n_tris == 44
+
+
+def test_vtk_sphere():
+    m = L.vtk_mesh_to_rtmesh(SPHERE, scale=2.0, world_position=np.array([0.0, 0.0, -4.0]))
+    assert m.element_count == 4992 and m.node_count == 2498 and m.timestep_count == 1
+    assert m.node_coords_expanded_over_time.shape == (1, 4992, 3, 3)
+    tris = m.node_coords_expanded_over_time[0] - np.array([0.0, 0.0, -4.0])
+    assert signed_volume(tris) == pytest.approx(4 / 3 * np.pi, rel=5e-3)  # radius 0.5 * 2, outward wound
+    assert np.allclose(np.linalg.norm(m.node_coords - np.array([0, 0, -4.0]), axis=1), 1.0, atol=1e-9)
+    m.set_surface(L.SurfType.FIELD_COLOR)
+    assert m.face_colors_over_time.shape == (1, 4992, 3) and np.all(m.face_colors_over_time == 0.5)
+    m.set_surface(L.SurfType.FIELD_COLOR, np.array([0.2, 0.4, 0.6]))
+    assert np.all(m.face_colors_over_time[0, 7] == [0.2, 0.4, 0.6])
+    sc = ra.Scene()
+    sc.add_rtmesh(m)
+    assert len(sc.coords_expanded) == 1 and len(sc.face_colors) == 1
+
+
+def test_reader_errors(tmp_path):
+    bad = tmp_path / "x.vtk"
+    bad.write_text("# vtk DataFile Version 2.0\nx\nBINARY\nDATASET UNSTRUCTURED_GRID\n")
+    with pytest.raises(ValueError):
+        L.vtk_mesh_to_rtmesh(bad)
