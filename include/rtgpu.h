@@ -92,7 +92,7 @@ int rt_upload_scene(rt_ctx *ctx, const rt_scene *scene);
 /* cpp/rtmathutils.h:15-19.  The context keeps the stream position in  */
 /* 32-bit outputs; rt_render() consumes H*W*spp*4 words per full image */
 /* exactly like render_ppm_image does.  Jitter pairs are generated on  */
-/* the GPU from jump-ahead states (GF(2) polynomial jump on the host). */
+/* the GPU from jump-ahead states (GF(2) polynomial jump, also on the GPU). */
 /* ------------------------------------------------------------------ */
 int rt_rng_seed(rt_ctx *ctx, uint32_t seed);          /* position 0 of mt19937(seed) */
 int rt_rng_seek(rt_ctx *ctx, uint64_t word_position); /* absolute position in the seeded stream */
@@ -101,6 +101,9 @@ uint64_t rt_rng_tell(const rt_ctx *ctx);
  * GPU by the same kernel rt_render uses, in `n_streams` jump-ahead streams.  Advances
  * the position by 2*n words. */
 int rt_rng_jitter(rt_ctx *ctx, int64_t n, int n_streams, double *out_host);
+/* Test seam: the context's device-resident generator state (the 624 raw words preceding the current
+ * position), as maintained by the GPU jump kernels. */
+int rt_rng_state(rt_ctx *ctx, uint32_t *state624);
 /* Host-only helpers (no GPU needed): the raw 624-word generator state that precedes
  * `word_position` of mt19937(seed), and n such states `stride` words apart.  The state is
  * the window x[p-624..p-1] of untempered words; the bits of the oldest word below bit 31

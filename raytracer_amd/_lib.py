@@ -65,6 +65,7 @@ _PROTOS = {
     "rt_rng_seek": (C.c_int, [_VP, C.c_uint64]),
     "rt_rng_tell": (C.c_uint64, [_VP]),
     "rt_rng_jitter": (C.c_int, [_VP, C.c_int64, C.c_int, _VP]),
+    "rt_rng_state": (C.c_int, [_VP, _VP]),
     "rt_mt19937_state_at": (C.c_int, [C.c_uint32, C.c_uint64, _VP]),
     "rt_mt19937_stream_states": (C.c_int, [C.c_uint32, C.c_uint64, C.c_uint64, C.c_int, _VP]),
     "rt_render": (C.c_int, [_VP, C.POINTER(RenderParams)]),

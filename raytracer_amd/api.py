@@ -127,6 +127,11 @@ class Context:
         L.check(lib.rt_rng_jitter(self.h, int(n), int(n_streams), L.ptr(out)), "rt_rng_jitter")
         return out
 
+    def rng_state(self):
+        out = np.empty(624, np.uint32)
+        L.check(lib.rt_rng_state(self.h, L.ptr(out)), "rt_rng_state")
+        return out
+
     # ---- render ----
     def render(self, cam, p00, spacing, H, W, spp, *, rows=None, jitter=None, hit_ids=False, hit_t=False,
                counters=False):

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -102,18 +103,21 @@ struct rt_ctx {
     int64_t n_tris = 0;
     // sampler
     uint32_t seed = 5489u;
-    uint64_t pos = 0;   // position of the global stream, in 32-bit outputs
-    rt::MtState state;  // state preceding `pos`
+    uint64_t pos = 0;            // position of the global stream, in 32-bit outputs
+    DevBuf<uint32_t> d_tmp;      // scratch state for in-place jumps
+    DevBuf<uint32_t> d_state;    // generator state preceding `pos` (624 raw words), device resident;
+                                 // every sampler operation is ordered on rng_stream
+    rt::MtState h_seed_state;    // host copy of the seeded state, kept alive for the async upload
+    std::map<uint64_t, unsigned long long*> d_polys;  // jump polynomials x^stride mod phi, uploaded once
     // Jitter slots: the pairs for one launch each.  While the traversal kernel of call n reads
     // slot A, the jitter kernel for the predicted call n+1 fills slot B on rng_stream.
     struct JitterSlot {
         DevBuf<double> buf;
-        DevBuf<uint32_t> d_states;
-        std::vector<rt::MtState> states;  // host copy: must outlive the async H2D copy
+        DevBuf<uint32_t> d_states;  // one state per stream
+        DevBuf<uint32_t> d_end;     // state preceding pos + rows*W*spp*4
         bool valid = false;
         uint64_t pos = 0;  // stream position the slot starts at
         int rows = 0, W = 0, spp = 0;
-        rt::MtState end_state;  // state preceding pos + rows*W*spp*4
         hipEvent_t done = nullptr, t0 = nullptr, t1 = nullptr;
         double host_ms = 0.0;
     } slot[2];
@@ -195,55 +199,110 @@ struct StreamPlan {
 
 StreamPlan plan_streams(int rows, int W, int spp) {
     StreamPlan p;
-    // at most 256 streams (one wave each), and no stream shorter than 2^18 words: the host
-    // pays one polynomial jump (~3 ms) per stream
+    // one wave per stream; jumps run on the GPU (~0.1 ms each, a level in parallel), so streams are
+    // cheap: up to 2048, none shorter than 2^16 words
     const uint64_t words = uint64_t(rows) * uint64_t(W) * uint64_t(spp) * 4u;
-    int target = (int)std::min<uint64_t>(256, std::max<uint64_t>(1, words >> 18));
+    int target = (int)std::min<uint64_t>(2048, std::max<uint64_t>(1, words >> 16));
     if (const char* e = std::getenv("RT_JITTER_STREAMS")) target = std::max(1, std::atoi(e));
     const int R = std::max(1, (rows + target - 1) / target);
     p.n = (rows + R - 1) / R;
     p.stride = uint64_t(R) * uint64_t(W) * uint64_t(spp) * 4u;
-    p.total_words = uint64_t(rows) * uint64_t(W) * uint64_t(spp) * 4u;
+    p.total_words = words;
     return p;
 }
 
-void compute_states(const rt::MtState& base, const StreamPlan& pl, std::vector<rt::MtState>& states,
-                    rt::MtState& end_state) {
-    rt::mt_stream_states(base, pl.stride, pl.n, host_threads(), states);
-    // state after the whole launch: jump from the last stream's start by the remainder
-    const uint64_t rem = pl.total_words - uint64_t(pl.n - 1) * pl.stride;
-    rt::mt_apply(rt::mt_jump_poly(rem), states[pl.n - 1], end_state);
+constexpr size_t kJumpLds = size_t(rtk::JUMP_LDS_WORDS) * sizeof(uint32_t);
+
+// Device copy of the jump polynomial x^stride mod phi (computed on the host once per stride).
+int dev_poly(rt_ctx* c, uint64_t stride, const unsigned long long** out) {
+    auto it = c->d_polys.find(stride);
+    if (it == c->d_polys.end()) {
+        const rt::MtPoly& g = rt::mt_jump_poly(stride);  // may throw
+        unsigned long long* d = nullptr;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d), sizeof(g.b)));
+        hipError_t e = hipMemcpy(d, g.b, sizeof(g.b), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(d);
+            return fail(RT_E_NO_DEVICE, std::string("hipMemcpy(poly) failed: ") + hipGetErrorString(e));
+        }
+        it = c->d_polys.emplace(stride, d).first;
+    }
+    *out = it->second;
+    return RT_OK;
 }
 
-int launch_jitter(DevBuf<uint32_t>& d_states, const std::vector<rt::MtState>& states, const StreamPlan& pl,
-                  double* d_out, hipStream_t st) {
-    int rc = d_states.ensure(size_t(pl.n) * rt::MT_N);
+// dst = state `stride` words after src (dst may alias src), on rng_stream.  The jump kernel
+// accumulates into a zeroed buffer with atomics, so an aliased jump goes through c->d_tmp.
+int dev_jump(rt_ctx* c, const uint32_t* src, uint32_t* dst, uint64_t stride) {
+    if (stride == 0) {
+        if (src != dst)
+            HIP_TRY(hipMemcpyAsync(dst, src, sizeof(rt::MtState), hipMemcpyDeviceToDevice, c->rng_stream));
+        return RT_OK;
+    }
+    const unsigned long long* poly = nullptr;
+    int rc = dev_poly(c, stride, &poly);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(d_states.p, states.data(), size_t(pl.n) * sizeof(rt::MtState), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(rtk::mt_jitter_kernel, dim3(pl.n), dim3(64), 0, st, d_states.p, d_out,
+    uint32_t* out = dst;
+    if (src == dst) {
+        if ((rc = c->d_tmp.ensure(rt::MT_N))) return rc;
+        out = c->d_tmp.p;
+    }
+    HIP_TRY(hipMemsetAsync(out, 0, sizeof(rt::MtState), c->rng_stream));
+    hipLaunchKernelGGL(rtk::mt_jump_kernel, dim3(1, rtk::JUMP_PARTS), dim3(rtk::JUMP_THREADS), kJumpLds, c->rng_stream,
+                       src, out, poly);
+    HIP_TRY(hipGetLastError());
+    if (out != dst) HIP_TRY(hipMemcpyAsync(dst, out, sizeof(rt::MtState), hipMemcpyDeviceToDevice, c->rng_stream));
+    return RT_OK;
+}
+
+// states[r] = state at base + r*stride for r in [0,n), states[0] given: doubling tree, one launch per level
+int dev_stream_states(rt_ctx* c, uint32_t* states, int n, uint64_t stride) {
+    if (n > 1) HIP_TRY(hipMemsetAsync(states + rt::MT_N, 0, size_t(n - 1) * sizeof(rt::MtState), c->rng_stream));
+    int levels = 0;
+    while ((1 << levels) < n) ++levels;
+    for (int k = levels - 1; k >= 0; --k) {
+        const int step = 1 << k;
+        const unsigned long long* poly = nullptr;
+        int rc = dev_poly(c, stride << k, &poly);
+        if (rc) return rc;
+        const int blocks = (n + 2 * step - 1) / (2 * step);
+        hipLaunchKernelGGL(rtk::mt_jump_tree_kernel, dim3(blocks, rtk::JUMP_PARTS), dim3(rtk::JUMP_THREADS), kJumpLds,
+                           c->rng_stream, states, poly, step, n);
+        HIP_TRY(hipGetLastError());
+    }
+    return RT_OK;
+}
+
+// stream states + jitter kernel for one launch, all on rng_stream; d_states[0] must hold the base state
+int launch_jitter(rt_ctx* c, uint32_t* d_states, const StreamPlan& pl, double* d_out) {
+    int rc = dev_stream_states(c, d_states, pl.n, pl.stride);
+    if (rc) return rc;
+    hipLaunchKernelGGL(rtk::mt_jitter_kernel, dim3(pl.n), dim3(64), 0, c->rng_stream, d_states, d_out,
                        (unsigned long long)(pl.stride / 2), (unsigned long long)(pl.total_words / 2));
     HIP_TRY(hipGetLastError());
     return RT_OK;
 }
 
-// Generate the jitter of one launch (rows x W x spp samples starting at stream position `pos`,
-// whose preceding state is `base`) into slot `k` on rng_stream.
-int fill_slot(rt_ctx* c, int k, const rt::MtState& base, uint64_t pos, int rows, int W, int spp) {
+// Generate the jitter of one launch (rows x W x spp samples starting `ahead` words after the
+// context's current position) into slot `k`, entirely on rng_stream.
+int fill_slot(rt_ctx* c, int k, uint64_t ahead, int rows, int W, int spp) {
     rt_ctx::JitterSlot& sl = c->slot[k];
     sl.valid = false;
     const size_t n_smp = size_t(rows) * size_t(W) * size_t(spp);
     int rc = sl.buf.ensure(n_smp * 2);
     if (rc) return rc;
     const StreamPlan pl = plan_streams(rows, W, spp);
+    if ((rc = sl.d_states.ensure(size_t(pl.n) * rt::MT_N))) return rc;
+    if ((rc = sl.d_end.ensure(rt::MT_N))) return rc;
     const double t0 = now_ms();
-    compute_states(base, pl, sl.states, sl.end_state);
-    sl.host_ms = now_ms() - t0;
     HIP_TRY(hipEventRecord(sl.t0, c->rng_stream));
-    rc = launch_jitter(sl.d_states, sl.states, pl, sl.buf.p, c->rng_stream);
-    if (rc) return rc;
+    if ((rc = dev_jump(c, c->d_state.p, sl.d_states.p, ahead))) return rc;
+    if ((rc = dev_jump(c, sl.d_states.p, sl.d_end.p, pl.total_words))) return rc;
+    if ((rc = launch_jitter(c, sl.d_states.p, pl, sl.buf.p))) return rc;
     HIP_TRY(hipEventRecord(sl.t1, c->rng_stream));
     HIP_TRY(hipEventRecord(sl.done, c->rng_stream));
-    sl.pos = pos;
+    sl.host_ms = now_ms() - t0;
+    sl.pos = c->pos + ahead;
     sl.rows = rows;
     sl.W = W;
     sl.spp = spp;
@@ -410,8 +469,12 @@ rt_ctx* rt_create(int device) {
     }
     std::unique_ptr<rt_ctx> c(new rt_ctx());
     c->device = device;
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->rng_stream, hipStreamNonBlocking) != hipSuccess) {
+    // the sampler stream gets the highest priority: its small kernels (jumps, jitter of the NEXT frame)
+    // must be dispatched between the workgroups of the long traversal kernel, not after it
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_lo) != hipSuccess ||
+        hipStreamCreateWithPriority(&c->rng_stream, hipStreamNonBlocking, prio_hi) != hipSuccess) {
         g_err = "rt_create: hipStreamCreate failed";
         return nullptr;
     }
@@ -426,9 +489,20 @@ rt_ctx* rt_create(int device) {
             g_err = "rt_create: hipEventCreate failed";
             return nullptr;
         }
-    rt::mt_seed(c->state, c->seed);
-    c->pos = 0;
-    return c.release();
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(rtk::mt_jump_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kJumpLds) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(rtk::mt_jump_tree_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kJumpLds) != hipSuccess) {
+        g_err = "rt_create: cannot reserve LDS for the jump kernels";
+        return nullptr;
+    }
+    if (c->d_state.ensure(rt::MT_N) != RT_OK) return nullptr;
+    rt_ctx* raw = c.release();
+    if (rt_rng_seed(raw, 5489u) != RT_OK) {
+        rt_destroy(raw);
+        return nullptr;
+    }
+    return raw;
 }
 
 void rt_destroy(rt_ctx* c) {
@@ -448,9 +522,14 @@ void rt_destroy(rt_ctx* c) {
     c->frame_params.release();
     c->d_states.release();
     c->jitter.release();
+    c->d_state.release();
+    c->d_tmp.release();
+    for (auto& kv : c->d_polys) (void)hipFree(kv.second);
+    c->d_polys.clear();
     for (auto& sl : c->slot) {
         sl.buf.release();
         sl.d_states.release();
+        sl.d_end.release();
         if (sl.done) (void)hipEventDestroy(sl.done);
         if (sl.t0) (void)hipEventDestroy(sl.t0);
         if (sl.t1) (void)hipEventDestroy(sl.t1);
@@ -525,8 +604,12 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* scene) {
 /* ------------------------------------------------------------------ sampler (context part) */
 int rt_rng_seed(rt_ctx* c, uint32_t seed) {
     if (!c) return fail(RT_E_INVALID, "rt_rng_seed: null context");
+    HIP_TRY(hipSetDevice(c->device));
+    // the previous upload of h_seed_state must have been consumed before it is overwritten
+    HIP_TRY(hipStreamSynchronize(c->rng_stream));
     c->seed = seed;
-    rt::mt_seed(c->state, seed);
+    rt::mt_seed(c->h_seed_state, seed);
+    HIP_TRY(hipMemcpyAsync(c->d_state.p, c->h_seed_state.w, sizeof(rt::MtState), hipMemcpyHostToDevice, c->rng_stream));
     c->pos = 0;
     for (auto& sl : c->slot) sl.valid = false;  // slots belong to the old seed's stream
     c->have_last_start = false;
@@ -536,20 +619,22 @@ int rt_rng_seed(rt_ctx* c, uint32_t seed) {
 int rt_rng_seek(rt_ctx* c, uint64_t word_position) {
     if (!c) return fail(RT_E_INVALID, "rt_rng_seek: null context");
     if (word_position == c->pos) return RT_OK;
+    HIP_TRY(hipSetDevice(c->device));
     try {
+        int rc;
         if (word_position > c->pos) {
-            rt::MtState o;
-            rt::mt_apply(rt::mt_jump_poly(word_position - c->pos), c->state, o);
-            c->state = o;
+            if ((rc = dev_jump(c, c->d_state.p, c->d_state.p, word_position - c->pos))) return rc;
         } else {
-            rt::MtState s, o;
-            rt::mt_seed(s, c->seed);
-            rt::mt_apply(rt::mt_jump_poly(word_position), s, o);
-            c->state = o;
+            HIP_TRY(hipStreamSynchronize(c->rng_stream));
+            rt::mt_seed(c->h_seed_state, c->seed);
+            HIP_TRY(hipMemcpyAsync(c->d_state.p, c->h_seed_state.w, sizeof(rt::MtState), hipMemcpyHostToDevice,
+                                   c->rng_stream));
+            if ((rc = dev_jump(c, c->d_state.p, c->d_state.p, word_position))) return rc;
         }
     } catch (const std::exception& e) {
         return fail(RT_E_INVALID, e.what());
     }
+    // slots prefetched relative to other positions stay valid: they are keyed by absolute position
     c->pos = word_position;
     return RT_OK;
 }
@@ -565,20 +650,27 @@ int rt_rng_jitter(rt_ctx* c, int64_t n, int n_streams, double* out_host) {
         pl.stride = per * 2;
         pl.n = int((uint64_t(n) + per - 1) / per);
         pl.total_words = uint64_t(n) * 2;
-        std::vector<rt::MtState> states;
-        rt::MtState end_state;
-        compute_states(c->state, pl, states, end_state);
         int rc = c->jitter.ensure(size_t(n));
         if (rc) return rc;
-        rc = launch_jitter(c->d_states, states, pl, c->jitter.p, c->rng_stream);
-        if (rc) return rc;
+        if ((rc = c->d_states.ensure(size_t(pl.n) * rt::MT_N))) return rc;
+        if ((rc = dev_jump(c, c->d_state.p, c->d_states.p, 0))) return rc;
+        if ((rc = launch_jitter(c, c->d_states.p, pl, c->jitter.p))) return rc;
+        if ((rc = dev_jump(c, c->d_state.p, c->d_state.p, pl.total_words))) return rc;
         HIP_TRY(hipMemcpyAsync(out_host, c->jitter.p, size_t(n) * sizeof(double), hipMemcpyDeviceToHost, c->rng_stream));
         HIP_TRY(hipStreamSynchronize(c->rng_stream));
-        c->state = end_state;
         c->pos += pl.total_words;
     } catch (const std::exception& e) {
         return fail(RT_E_INVALID, e.what());
     }
+    return RT_OK;
+}
+
+/* Test seam: the device-resident generator state (624 raw words preceding the current position). */
+int rt_rng_state(rt_ctx* c, uint32_t* state624) {
+    if (!c || !state624) return fail(RT_E_INVALID, "rt_rng_state: null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(state624, c->d_state.p, sizeof(rt::MtState), hipMemcpyDeviceToHost, c->rng_stream));
+    HIP_TRY(hipStreamSynchronize(c->rng_stream));
     return RT_OK;
 }
 
@@ -634,12 +726,13 @@ int rt_render(rt_ctx* c, const rt_render_params* p) {
             }
             if (use < 0) {
                 use = 1 - c->last_slot;
-                if ((rc = fill_slot(c, use, c->state, c->pos, rows, W, spp))) return rc;
+                if ((rc = fill_slot(c, use, 0, rows, W, spp))) return rc;
                 c->stats.host_jump_ms = c->slot[use].host_ms;
             }
             HIP_TRY(hipStreamWaitEvent(c->stream, c->slot[use].done, 0));
             c->jitter_timed = true;
-            c->state = c->slot[use].end_state;
+            HIP_TRY(hipMemcpyAsync(c->d_state.p, c->slot[use].d_end.p, sizeof(rt::MtState), hipMemcpyDeviceToDevice,
+                                   c->rng_stream));
             c->pos += uint64_t(n_smp) * 4u;
             c->slot[use].valid = false;  // consumed
             c->last_slot = use;
@@ -760,12 +853,10 @@ int rt_render(rt_ctx* c, const rt_render_params* p) {
                 const uint64_t delta = start_pos - c->last_start;
                 if (delta >= uint64_t(n_smp) * 4u) next = start_pos + delta;
             }
-            rt::MtState base = c->state;
-            if (next != c->pos) rt::mt_apply(rt::mt_jump_poly(next - c->pos), c->state, base);
             const int other = 1 - use;
             // slot `other` was last read by the previous call's kernel, which has completed
             // (stream synchronised on entry); its own jitter kernel is ordered on rng_stream.
-            if ((rc = fill_slot(c, other, base, next, rows, W, spp))) return rc;
+            if ((rc = fill_slot(c, other, next - c->pos, rows, W, spp))) return rc;
         } catch (const std::exception&) {
             c->slot[1 - use].valid = false;
         }

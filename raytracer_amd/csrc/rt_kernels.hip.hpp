@@ -984,4 +984,117 @@ __global__ __launch_bounds__(64) void mt_jitter_kernel(const uint32_t* __restric
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// MT19937 jump-ahead on the GPU:  dst = g(A) src  for a polynomial g over GF(2) (312 x 64 bit,
+// degree < 19937), A the generator's one-word transition.  With x[0..623] = src (the window of
+// raw words preceding the position) and x[624..] the raw words the generator produces from it,
+// A^i src is the window x[i .. i+623], so
+//        dst[j] = XOR over the set bits i of g of x[i + j],        j = 0..623.
+// Eight 256-thread workgroups per jump, each owning 2496 consecutive coefficients of g: a part
+// regenerates the words it needs in LDS 227 at a time (word n needs n-624, n-623 and n-227: all
+// older than the chunk), then each lane walks the set bits of its slice of g (a wave-uniform,
+// scalar loop) and XORs x[i+j] -- consecutive lanes read consecutive words, conflict-free -- and
+// the parts combine with atomic XORs.  Small workgroups (15.5 KB LDS) so they are dispatched
+// between the workgroups of a running traversal kernel.  The host only supplies the polynomials
+// (cached per stride).  Bits 0..30 of dst[0] are not part of the generator's
+// state and come out unspecified, exactly as in the host implementation.
+// ---------------------------------------------------------------------------------------
+constexpr int JUMP_THREADS = 256;  // same footprint as a traversal workgroup: slots in between them
+constexpr int JUMP_PARTS = 8;      // workgroups per jump; each takes 39 of g's 312 words (2496 coefficients)
+constexpr int JUMP_SPAN = (312 / JUMP_PARTS) * 64;                  // 2496 = 4 generator blocks
+constexpr int JUMP_WORDS = 624 + JUMP_SPAN;                         // window a part reads: x[i+j]
+constexpr int JUMP_LDS_WORDS = JUMP_WORDS + 3 * JUMP_THREADS;       // + zero words (15.5 KB in all)
+static_assert(JUMP_SPAN % 624 == 0, "a part's first coefficient must sit on a generator block boundary");
+
+// Workgroup `part` of JUMP_PARTS XORs its share of  dst[j] ^= x[i + j]  (i over the set bits of its
+// slice of g) into dst with atomics; dst must be zero beforehand.  The part first advances the source
+// state by part*JUMP_SPAN words (whole 624-word blocks, regenerated in place), then extends it
+// linearly by JUMP_SPAN words, so only a 3120-word window lives in LDS.
+__device__ __forceinline__ void mt_jump_block(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
+                                              const unsigned long long* __restrict__ poly, const int part,
+                                              uint32_t* x) {
+    const int tid = threadIdx.x;
+    for (int k = tid; k < 624; k += JUMP_THREADS) x[k] = src[k];
+    x[JUMP_WORDS + tid] = 0u;
+    x[JUMP_WORDS + JUMP_THREADS + tid] = 0u;
+    x[JUMP_WORDS + 2 * JUMP_THREADS + tid] = 0u;
+    __syncthreads();
+    // advance by whole blocks, in place: three chunks of <= 227 words, reads before writes
+    for (int blk = 0; blk < part * (JUMP_SPAN / 624); ++blk) {
+        for (int c0 = 0; c0 < 624; c0 += 227) {
+            const int k = c0 + tid;
+            uint32_t nw = 0;
+            const bool on = tid < 227 && k < 624;
+            if (on) {
+                const uint32_t xa = x[k];
+                const uint32_t xb = x[(k + 1 == 624) ? 0 : k + 1];
+                const uint32_t xm = x[(k + 397 >= 624) ? k + 397 - 624 : k + 397];
+                const uint32_t y = (xa & 0x80000000u) | (xb & 0x7fffffffu);
+                nw = xm ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            }
+            __syncthreads();
+            if (on) x[k] = nw;
+            __syncthreads();
+        }
+    }
+    // linear extension: word n needs n-624, n-623 and n-227, all older than its chunk
+    for (int base = 624; base < JUMP_WORDS; base += 227) {
+        const int n = base + tid;
+        if (tid < 227 && n < JUMP_WORDS) {
+            const uint32_t xa = x[n - 624], xb = x[n - 623], xm = x[n - 227];
+            const uint32_t y = (xa & 0x80000000u) | (xb & 0x7fffffffu);
+            x[n] = xm ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        __syncthreads();
+    }
+    const RT_CONST unsigned long long* g =
+        (const RT_CONST unsigned long long*)(const void*)(poly + part * (312 / JUMP_PARTS));
+    // lane handles j = tid, tid + 256 and (tid < 112) tid + 512; the third read of the other lanes
+    // stays inside the zero-padded buffer and is discarded
+    uint32_t a0 = 0, a1 = 0, a2 = 0;
+    const uint32_t* xj = x + tid;
+    for (int w = 0; w < 312 / JUMP_PARTS; ++w) {
+        unsigned long long bits = g[w];  // scalar load: the loop over set bits is wave-uniform
+        const uint32_t* xw = xj + 64 * w;
+        while (bits) {
+            // two set bits per trip: six LDS reads in flight
+            const int b0 = __builtin_ctzll(bits);
+            bits &= bits - 1ull;
+            const bool more = bits != 0ull;
+            const int b1 = more ? __builtin_ctzll(bits) : 0;
+            bits &= bits - 1ull;
+            const uint32_t* p0 = xw + b0;
+            const uint32_t* p1 = more ? xw + b1 : x + JUMP_WORDS + tid;  // zeros
+            const uint32_t u0 = p0[0], u1 = p0[JUMP_THREADS], u2 = p0[2 * JUMP_THREADS];
+            const uint32_t v0 = p1[0], v1 = p1[JUMP_THREADS], v2 = p1[2 * JUMP_THREADS];
+            a0 ^= u0 ^ v0;
+            a1 ^= u1 ^ v1;
+            a2 ^= u2 ^ v2;
+        }
+    }
+    atomicXor(&dst[tid], a0);
+    atomicXor(&dst[tid + JUMP_THREADS], a1);
+    if (tid + 2 * JUMP_THREADS < 624) atomicXor(&dst[tid + 2 * JUMP_THREADS], a2);
+}
+
+// single jump: dst ^= g(A) src, dst zeroed by the caller and distinct from src.  grid (1, JUMP_PARTS)
+__global__ __launch_bounds__(JUMP_THREADS) void mt_jump_kernel(const uint32_t* src, uint32_t* dst,
+                                                               const unsigned long long* poly) {
+    extern __shared__ uint32_t jump_x[];
+    mt_jump_block(src, dst, poly, blockIdx.y, jump_x);
+}
+
+// one level of the doubling tree over an array of stream states (all but states[0] zeroed beforehand):
+// blocks (q, part) compute states[q*2*step + step] = g(A) states[q*2*step]   (g = x^(stride*step));
+// blocks whose target lies beyond n do nothing.  grid (ceil(n / 2step), JUMP_PARTS)
+__global__ __launch_bounds__(JUMP_THREADS) void mt_jump_tree_kernel(uint32_t* states, const unsigned long long* poly,
+                                                                    const int step, const int n) {
+    extern __shared__ uint32_t jump_x[];
+    const long long srci = (long long)blockIdx.x * 2 * step;
+    const long long dsti = srci + step;
+    if (dsti >= n) return;
+    mt_jump_block(states + srci * 624, states + dsti * 624, poly, blockIdx.y, jump_x);
+}
+
 }  // namespace rtk

@@ -345,3 +345,33 @@ def test_reference_sample_files_render_like_the_oracle(ctx, tmp_path):
         got, want, _ = check_image(ctx, [b.node_coords_expanded_over_time], [b.face_colors_over_time],
                                    meshgen.camera_arrays(100, 56), 56, 100, 1, timestep=t)
         assert (want["hit_elem"] >= 0).mean() > 0.05
+
+
+def test_device_jump_matches_host_jump_and_sequential(ctx):
+    """The GPU jump kernels (seek, stream doubling tree) against the host GF(2) jump and sequential generation."""
+    from test_mt_jump import oracle_words_from_state
+    for pos in (1, 623, 624, 1000, 360000, 2**33 + 12346):
+        ctx.rng_seed(5489)
+        ctx.rng_seek(pos)
+        dev = ctx.rng_state()
+        host = ra.mt19937_state_at(pos)
+        assert np.array_equal(dev[1:], host[1:]) and (dev[0] >> 31) == (host[0] >> 31), pos
+        assert np.array_equal(oracle_words_from_state(dev, 700), oracle_words_from_state(host, 700))
+    # far position, many streams, then a backward seek
+    ctx.rng_seed(5489)
+    ctx.rng_seek(2**40 + 6)
+    got = ctx.rng_jitter(50000, 37)
+    g = orc.Rng()
+    g.set_state(ra.mt19937_state_at(2**40 + 6))
+    assert np.array_equal(bits(got), bits(g.doubles(50000) - 0.5))
+    assert ctx.rng_tell() == 2**40 + 6 + 100000
+    ctx.rng_seek(10)
+    got = ctx.rng_jitter(100, 1)
+    g = orc.Rng()
+    g.discard(10)
+    assert np.array_equal(bits(got), bits(g.doubles(100) - 0.5))
+    # other seed
+    ctx.rng_seed(42)
+    got = ctx.rng_jitter(1000, 3)
+    assert np.array_equal(bits(got), bits(orc.Rng(42).doubles(1000) - 0.5))
+    ctx.rng_seed(5489)
