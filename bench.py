@@ -115,6 +115,66 @@ def cpu_baseline(coords, colors, cam, H, W, spp, ctx_check, host, budget_rays):
                                    rows_checked=len(rows)) if ctx_check is not None else None)
 
 
+def bench_multiframe(ra, rank, world, local_rank, dist, steps_per_rank=16):
+    """frames/s of rt_render_scene on a displacement sequence: 8 meshes x 32,768 triangles, 2 cameras,
+    1024x576, 50 spp, `steps_per_rank * world` timesteps (each rank renders its share of the frames)."""
+    import ctypes as C
+    import tempfile
+    from raytracer_amd import _lib as L, meshgen
+    T = steps_per_rank * world
+    H, W, spp = 576, 1024, 50
+    coords, colors = [], []
+    for m in range(8):
+        c, k = meshgen.plate(128, side=5.0, x0=-10.0 + 5.0 * (m % 4), y0=-5.0 + 5.0 * (m // 4), z0=-6.0, T=T, sway=0.01)
+        coords.append(np.ascontiguousarray(c))
+        colors.append(np.ascontiguousarray(k))
+    cams = [meshgen.camera_arrays(W, H, center=(-0.3, 0.0, 0.0), target=(0.0, 0.0, -6.0), fov=80),
+            meshgen.camera_arrays(W, H, center=(0.3, 0.0, 0.0), target=(0.0, 0.0, -6.0), fov=80)]
+    cc = np.ascontiguousarray(np.array([c[0] for c in cams], np.float64))
+    p00 = np.ascontiguousarray(np.array([c[1] for c in cams], np.float64))
+    sp = np.ascontiguousarray(np.array([c[2] for c in cams], np.float64).reshape(2, 6))
+    cp = (C.c_void_p * 8)(*[c.ctypes.data for c in coords])
+    kp = (C.c_void_p * 8)(*[k.ctypes.data for k in colors])
+    counts = np.array([k.shape[1] for k in colors], np.int64)
+    out_dir = tempfile.mkdtemp(prefix=f"rtbench_r{rank}_")
+
+    def run(n_steps):
+        # the driver prints the reference's progress lines: keep them off our one-JSON-line stdout
+        sys.stdout.flush()
+        saved = os.dup(1)
+        devnull = os.open(os.devnull, os.O_WRONLY)
+        os.dup2(devnull, 1)
+        try:
+            rc = L.lib.rt_render_scene(H, W, spp, out_dir.encode(), n_steps, 8, cp, kp, L.ptr(counts), 2, L.ptr(cc),
+                                       L.ptr(p00), L.ptr(sp), local_rank, rank, world)
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
+            os.close(devnull)
+        L.check(rc, "rt_render_scene")
+
+    run(min(T, 2 * world))  # warm-up: polynomials, allocations
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    run(T)
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    n_files = len([f for f in os.listdir(out_dir) if f.endswith(".ppm")])
+    for f in os.listdir(out_dir):
+        os.remove(os.path.join(out_dir, f))
+    os.rmdir(out_dir)
+    frames = T * 2
+    return {"frames_per_s": frames / elapsed, "frames": frames, "seconds": elapsed, "image": [H, W], "spp": spp,
+            "meshes": 8, "triangles": int(counts.sum()), "cameras": 2, "timesteps": T,
+            "mrays_per_s": frames * H * W * spp / elapsed / 1e6, "files_written_by_rank0": n_files,
+            "includes": "per-timestep host BVH build (overlapped), upload, render, read-back, P6 write"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -123,6 +183,7 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("RT_BENCH_WORKLOAD", "c4"))
     ap.add_argument("--cpu-rays", type=float, default=12e6, help="rays in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-hit-ids", action="store_true")
+    ap.add_argument("--no-multiframe", action="store_true", help="skip the frames/s (multi-frame driver) measurement")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -188,6 +249,11 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # second metric of BASELINE.json ("frames/s multi-frame render"): the whole reference loop through
+    # rt_render_scene -- per-timestep host BVH rebuild (TLAS + 8 BLAS), upload, 2 cameras x 50 spp,
+    # read-back, P6 files -- frames sharded over ranks, no collective.  configs[4]-shaped, weak scaling.
+    multiframe = None if args.no_multiframe else bench_multiframe(ra, rank, world, local_rank, dist)
 
     # untimed extras on rank 0: per-launch kernel time over several launches, visit counters, CPU baseline
     out = None
@@ -262,7 +328,8 @@ def main():
             "aux": {"jitter_kernel_ms": jms, "host_jump_ms_per_frame": hjm, "host_bvh_build_s": build_s,
                     "upload_s": upload_s, "stack_need": int(host.info.stack_need),
                     "download_frame_ms": dl_frame_ms, "download_hit_ids_ms": dl_ids_ms,
-                    "kernel_ms_timed_step": kernel_ms[-1] if kernel_ms else None},
+                    "kernel_ms_timed_step": kernel_ms[-1] if kernel_ms else None,
+                    "multiframe": multiframe},
         }
     if dist is not None:
         dist.barrier()

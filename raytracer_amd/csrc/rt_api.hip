@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <future>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -1023,20 +1024,53 @@ int rt_render_scene(int image_height, int image_width, int number_of_samples, co
     std::vector<int64_t> my_frames((size_t)std::max<int64_t>(n_mine, 1));
     std::vector<uint64_t> my_pos((size_t)std::max<int64_t>(n_mine, 1));
     rt_shard_frames(timestep_count, n_cameras, rank, world, base, frame_words, n_mine, my_frames.data(), my_pos.data());
+    // The host BVH build of the NEXT timestep this rank renders runs on a helper thread while the GPU
+    // renders the current one (the build is per frame and would otherwise serialise with the render).
+    std::vector<int> my_steps;
+    for (int64_t q = 0; q < n_mine; ++q) {
+        const int t = (int)(my_frames[q] / n_cameras);
+        if (my_steps.empty() || my_steps.back() != t) my_steps.push_back(t);
+    }
+    struct Built {
+        rt_scene* sc = nullptr;
+        std::string err;
+    };
+    auto build_async = [&](int t) {
+        return std::async(std::launch::async, [=]() {
+            Built b;
+            b.sc = rt_scene_build(n_meshes, coords, colors, elem_counts, t, 0);
+            if (!b.sc) b.err = rt_last_error();  // thread-local message of the helper thread
+            return b;
+        });
+    };
+    std::future<Built> pending;
+    size_t next_step = 0;
+    if (!my_steps.empty()) pending = build_async(my_steps[next_step++]);
     int built_t = -1;
     for (int64_t q = 0; q < n_mine; ++q) {
         const int t = (int)(my_frames[q] / n_cameras), cam = (int)(my_frames[q] % n_cameras);
         if (t != built_t) {  // frames arrive timestep-major: one build per timestep this rank touches
-            rt_scene* sc = rt_scene_build(n_meshes, coords, colors, elem_counts, t, 0);
-            if (!sc) return RT_E_INVALID;
-            for (int64_t k = 0; k < sc->s->midpoint_fallbacks; ++k)
+            Built b = pending.get();
+            if (next_step < my_steps.size()) pending = build_async(my_steps[next_step++]);
+            if (!b.sc) {
+                if (pending.valid()) rt_scene_free(pending.get().sc);
+                return fail(RT_E_INVALID, b.err);
+            }
+            for (int64_t k = 0; k < b.sc->s->midpoint_fallbacks; ++k)
                 std::printf("SAH splitting failed. Trying midpoint instead.\n");  // cpp/rtbvh.cpp:128
-            rc = rt_upload_scene(c, sc);
-            rt_scene_free(sc);
-            if (rc) return rc;
+            rc = rt_upload_scene(c, b.sc);
+            rt_scene_free(b.sc);
+            if (rc) {
+                if (pending.valid()) rt_scene_free(pending.get().sc);
+                return rc;
+            }
             built_t = t;
         }
-        if ((rc = rt_rng_seek(c, my_pos[q]))) return rc;
+        auto bail = [&](int code) {
+            if (pending.valid()) rt_scene_free(pending.get().sc);
+            return code;
+        };
+        if ((rc = rt_rng_seek(c, my_pos[q]))) return bail(rc);
         std::printf("Rendering frame %d/%d\n", t + 1, timestep_count);  // cpp/rtmain.cpp:61
         std::fflush(stdout);
         rt_render_params p;
@@ -1050,8 +1084,8 @@ int rt_render_scene(int image_height, int image_width, int number_of_samples, co
         p.row_begin = 0;
         p.row_end = image_height;
         p.sampler = RT_SAMPLER_MT19937;
-        if ((rc = rt_render(c, &p))) return rc;
-        if ((rc = rt_download(c, nullptr, rgb.data(), nullptr, nullptr))) return rc;
+        if ((rc = rt_render(c, &p))) return bail(rc);
+        if ((rc = rt_download(c, nullptr, rgb.data(), nullptr, nullptr))) return bail(rc);
         // cpp/rtmain.cpp:58-60: rtimage_<timestep>_cam<camera>.ppm, zero-based
         std::string path = std::string(output_directory) + "/rtimage_" + std::to_string(t) + "_cam" +
                            std::to_string(cam) + ".ppm";
