@@ -293,10 +293,19 @@ def main():
         bray = b_ray(cs["nodes_visited"], cs["tris_tested"], cs["rays_hit"], cs["rays"], spp)
         achieved = rays_per_frame * bray / (kms * 1e-3) / 1e9
         traffic = None
+        valu = None
         pmc_path = os.path.join(ROOT, "profiles", f"pmc_{args.workload}.json")
         if os.path.exists(pmc_path):
             try:
-                traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+                pmc = json.load(open(pmc_path))
+                traffic = pmc.get("hbm_bytes_per_launch")
+                # the bound that actually binds: non-fused fp64 VALU issue, 256 CU x 4 SIMD x
+                # 16 lanes x 2.4 GHz = 39.3 T lane-ops/s; instruction count from the committed PMC pass
+                vi = pmc.get("void rtk::render_packet_kernel<false>", {}).get("SQ_INSTS_VALU")
+                if vi:
+                    valu = {"lane_ops_per_launch": vi * 64, "peak_lane_ops_per_s": 39.3e12,
+                            "frac_of_fp64_issue_peak": vi * 64 / (kms * 1e-3) / 39.3e12,
+                            "source": "profiles/pmc_%s.json (SQ_INSTS_VALU x 64)" % args.workload}
             except Exception:
                 traffic = None
         # host hand-over cost (PCIe), never part of `value`
@@ -344,7 +353,8 @@ def main():
                          "rays_per_launch": rays_per_frame, "nodes_per_ray": cs["nodes_visited"] / cs["rays"],
                          "tris_per_ray": cs["tris_tested"] / cs["rays"], "hit_rate": cs["rays_hit"] / cs["rays"],
                          "kernel_only_mrays_s": rays_per_frame / (kms * 1e-3) / 1e6,
-                         "wave_node_fetches_per_ray": cs["wave_node_fetches"] / cs["rays"]},
+                         "wave_node_fetches_per_ray": cs["wave_node_fetches"] / cs["rays"],
+                         "valu": valu},
             "cpu_baseline": cpu,
             "aux": {"jitter_kernel_ms": jms, "host_jump_ms_per_frame": hjm, "host_bvh_build_s": build_s,
                     "upload_s": upload_s, "stack_need": int(host.info.stack_need),
