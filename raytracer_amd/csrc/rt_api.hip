@@ -792,7 +792,9 @@ int rt_render(rt_ctx* c, const rt_render_params* p) {
         a.hit_prim = (p->flags & RT_FLAG_HIT_IDS) ? c->hit_prim.p : nullptr;
         a.hit_t = (p->flags & RT_FLAG_HIT_T) ? c->hit_t.p : nullptr;
         a.counters = count ? c->counters.p : nullptr;
-        a.fast_ok = (c->max_abs_coord + std::fabs(ox) + std::fabs(oy) + std::fabs(oz)) < 1e100 ? 1 : 0;
+        // finite coordinates => every node box (>= 1 triangle, rt_scene_build rejects empty meshes) has
+        // min <= max, and so has its camera-relative copy (subtraction rounds monotonically): level 2
+        a.fast_ok = (c->max_abs_coord + std::fabs(ox) + std::fabs(oy) + std::fabs(oz)) < 1e100 ? 2 : 0;
         HIP_TRY(hipEventRecord(c->ev[0], c->stream));
         if (count)
             hipLaunchKernelGGL(rtk::render_packet_kernel<true>, dim3((unsigned)n_tiles), dim3(rtk::NT), 0, c->stream, a);

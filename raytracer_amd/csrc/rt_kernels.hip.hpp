@@ -484,8 +484,24 @@ __device__ __forceinline__ void sload_node(const rt::DevNode* p, SBox& b, int32_
 // std::max composition whenever no operand is NaN: the results are then only compared, and
 // comparisons do not see the sign of a zero).  The caller selects FAST only for waves in which
 // no lane has an infinite inverse-direction component (the only source of 0*inf = NaN).
-template <bool FAST>
+// OCT >= 0 (only with FAST): every active lane of the wave has the same sign of ix, of iy and of iz
+// (sx/sy/sz = that component is negative).  With
+// mn <= mx per axis (every node bounds at least one triangle) and rounding monotone, the product
+// with the near plane IS min(t_lo, t_hi) and the far one IS max(t_lo, t_hi), so the six inner
+// min/max of intersect_AABB (rtrayintersection.cpp:136-141) are known without computing them.
+// OCT = -1: mixed signs; else bit0/1/2 = ix/iy/iz negative (compile-time: a run-time select, even a
+// wave-uniform one, is turned into v_cndmask on the products by the compiler).
+template <bool FAST, int OCT>
 __device__ __forceinline__ unsigned long long slab_rel(const SBox& b, const double ix, const double iy, const double iz) {
+    if (FAST && OCT >= 0) {
+        constexpr bool sx = (OCT & 1) != 0, sy = (OCT & 2) != 0, sz = (OCT & 4) != 0;
+        const double nx = sx ? b.mxx : b.mnx, fx = sx ? b.mnx : b.mxx;
+        const double ny = sy ? b.mxy : b.mny, fy = sy ? b.mny : b.mxy;
+        const double nz = sz ? b.mxz : b.mnz, fz = sz ? b.mnz : b.mxz;
+        const double tmin = __builtin_fmax(__builtin_fmax(nx * ix, ny * iy), nz * iz);
+        const double tmax = __builtin_fmin(__builtin_fmin(fx * ix, fy * iy), fz * iz);
+        return __builtin_amdgcn_ballot_w64(tmin <= tmax) & __builtin_amdgcn_ballot_w64(tmax > 0.0);
+    }
     const double t0 = b.mnx * ix, t1 = b.mxx * ix;
     const double t2 = b.mny * iy, t3 = b.mxy * iy;
     const double t4 = b.mnz * iz, t5 = b.mxz * iz;
@@ -513,11 +529,10 @@ struct WaveCounters {
     unsigned long long steps;        // node records fetched by the wave (the packet's own work)
 };
 
-template <bool FAST, bool COUNT>
+template <bool FAST, int OCT, bool COUNT>
 __device__ __forceinline__ void trace_packet(const PacketScene& sc, const unsigned long long valid_mask,
-                                             const double dx, const double dy, const double dz, const double ix,
-                                             const double iy, const double iz, uint4* wstk, Hit& h,
-                                             WaveCounters& wc) {
+                                          const double dx, const double dy, const double dz, const double ix,
+                                          const double iy, const double iz, uint4* wstk, Hit& h, WaveCounters& wc) {
     int sp = 0;
     uint32_t cur = rt::DESC_TLAS;
     unsigned long long inm = valid_mask;
@@ -554,8 +569,8 @@ __device__ __forceinline__ void trace_packet(const PacketScene& sc, const unsign
                 wc.nodes += 2u * (unsigned)__builtin_popcountll(inm);
                 wc.steps += 2u;
             }
-            const unsigned long long ml = slab_rel<FAST>(bl, ix, iy, iz) & inm;
-            const unsigned long long mr = slab_rel<FAST>(br, ix, iy, iz) & inm;
+            const unsigned long long ml = slab_rel<FAST, OCT>(bl, ix, iy, iz) & inm;
+            const unsigned long long mr = slab_rel<FAST, OCT>(br, ix, iy, iz) & inm;
             if (ml != 0ull) {
                 if (mr != 0ull) wstk[sp++] = make_uint4(dr, (uint32_t)mr, (uint32_t)(mr >> 32), 0u);
                 cur = dl;
@@ -614,7 +629,7 @@ __device__ __forceinline__ void trace_packet(const PacketScene& sc, const unsign
                 if (cur & rt::DESC_TLAS) {
                     sload_node(sc.tlas + (cur & 0x3FFFFFFFu), b, left, count, first, desc);
                     if (COUNT) wc.nodes += (unsigned)__builtin_popcountll(inm);
-                    const unsigned long long hm = slab_rel<FAST>(b, ix, iy, iz) & inm;
+                    const unsigned long long hm = slab_rel<FAST, OCT>(b, ix, iy, iz) & inm;
                     if (hm != 0ull) {
                         const uint32_t lo = (uint32_t)hm, hi = (uint32_t)(hm >> 32);
                         if (left < 0) {
@@ -630,7 +645,7 @@ __device__ __forceinline__ void trace_packet(const PacketScene& sc, const unsign
                     const int32_t root = sr[cur & 0x1FFFFFFFu];
                     sload_node(sc.nodes + root, b, left, count, first, desc);
                     if (COUNT) wc.nodes += (unsigned)__builtin_popcountll(inm);
-                    const unsigned long long hm = slab_rel<FAST>(b, ix, iy, iz) & inm;
+                    const unsigned long long hm = slab_rel<FAST, OCT>(b, ix, iy, iz) & inm;
                     if (hm != 0ull) {
                         cur = desc;
                         inm = hm;
@@ -669,7 +684,7 @@ struct PacketArgs {
     int32_t* hit_prim;
     double* hit_t;
     unsigned long long* counters;
-    int32_t fast_ok;  // host: every |node coordinate - camera| < 1e100
+    int32_t fast_ok;  // host: >= 1: every |node coordinate - camera| < 1e100; 2: and every box has min <= max
 };
 
 constexpr int PACKET_STACK = 128;  // entries of the per-wave LDS stack ({descriptor, lane mask}, 16 B each)
@@ -757,10 +772,34 @@ __global__ __launch_bounds__(NT, 8) void render_packet_kernel(const PacketArgs a
         const unsigned long long amask = __builtin_amdgcn_ballot_w64(active);
         if (amask != 0ull) {
             WaveCounters wc = {0ull, 0ull, 0ull};
-            if (__builtin_amdgcn_ballot_w64(risky) != 0ull)
-                trace_packet<false, COUNT>(a.sc, amask, dx, dy, dz, ix, iy, iz, wstk, h, wc);
-            else
-                trace_packet<true, COUNT>(a.sc, amask, dx, dy, dz, ix, iy, iz, wstk, h, wc);
+            // per axis: do all active lanes look the same way?  (inactive lanes are masked out of every result)
+            const unsigned long long ngx = __builtin_amdgcn_ballot_w64(ix < 0.0) & amask;
+            const unsigned long long ngy = __builtin_amdgcn_ballot_w64(iy < 0.0) & amask;
+            const unsigned long long ngz = __builtin_amdgcn_ballot_w64(iz < 0.0) & amask;
+            const bool uni = (ngx == 0ull || ngx == amask) && (ngy == 0ull || ngy == amask) &&
+                             (ngz == 0ull || ngz == amask) && a.fast_ok == 2;
+            if (__builtin_amdgcn_ballot_w64(risky) != 0ull) {
+                trace_packet<false, -1, COUNT>(a.sc, amask, dx, dy, dz, ix, iy, iz, wstk, h, wc);
+            } else if (uni) {
+                const int oct = (ngx != 0ull ? 1 : 0) | (ngy != 0ull ? 2 : 0) | (ngz != 0ull ? 4 : 0);
+                switch (oct) {
+#define RT_OCT_CASE(O)                                                                          \
+    case O:                                                                                     \
+        trace_packet<true, O, COUNT>(a.sc, amask, dx, dy, dz, ix, iy, iz, wstk, h, wc);         \
+        break;
+                    RT_OCT_CASE(0)
+                    RT_OCT_CASE(1)
+                    RT_OCT_CASE(2)
+                    RT_OCT_CASE(3)
+                    RT_OCT_CASE(4)
+                    RT_OCT_CASE(5)
+                    RT_OCT_CASE(6)
+                    RT_OCT_CASE(7)
+#undef RT_OCT_CASE
+                }
+            } else {
+                trace_packet<true, -1, COUNT>(a.sc, amask, dx, dy, dz, ix, iy, iz, wstk, h, wc);
+            }
             if (COUNT && lane == 0) {
                 w_nodes += wc.nodes;
                 w_tris += wc.tris;

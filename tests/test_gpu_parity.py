@@ -142,6 +142,33 @@ def test_render_odd_sizes_and_stream_position(ctx):
     check_image(ctx, [c], [k], cam, 70, 3, 2)
 
 
+def _cloud(n, seed, extent=5.0, size=0.5):
+    """Randomly oriented triangles all around the origin (about half face any given viewer)."""
+    rng = np.random.default_rng(seed)
+    c = rng.uniform(-extent, extent, (n, 3))
+    c = c[np.linalg.norm(c, axis=1) > 1.0]
+    arr = c[:, None, :] + rng.uniform(-size, size, (c.shape[0], 3, 3))
+    g = rng.uniform(0.05, 0.95, (c.shape[0], 3))  # genuinely RGB face colours
+    return np.ascontiguousarray(arr[None]), np.ascontiguousarray(g[None])
+
+
+@pytest.mark.parametrize("spp", [2, 64])
+def test_every_direction_octant_and_mixed_sign_waves(ctx, spp):
+    """The packet kernel specialises its slab test per direction octant when a whole wave looks the same
+    way: cameras towards all 8 octants (wave-uniform signs) and along the 6 axes (signs
+    mixed inside a wave) must give the oracle's image."""
+    c, k = _cloud(6000, 11)
+    targets = [(sx, sy, sz) for sx in (-1.0, 1.0) for sy in (-0.9, 1.1) for sz in (-1.2, 0.8)]
+    targets += [(1.0, 0.01, 0.02), (-1.0, 0.02, 0.01), (0.01, 0.02, 1.0), (0.02, 0.01, -1.0), (0.03, 1.0, 0.2),
+                (0.01, -1.0, 0.2)]
+    hits = 0
+    for i, t in enumerate(targets):
+        cam = meshgen.camera_arrays(24, 16, center=(0.05, -0.03, 0.02), target=t, fov=60 if i < 8 else 100)
+        got, want, _ = check_image(ctx, [c], [k], cam, 16, 24, spp, seed_pos=4 * 1000 * i)
+        hits += int((want["hit_elem"] >= 0).sum())
+    assert hits > 14 * 16 * 24 * spp * 0.2
+
+
 @pytest.mark.parametrize("n_meshes", [2, 3, 5, 8])
 def test_render_multi_mesh_including_slot_quirk(ctx, n_meshes):
     rng = np.random.default_rng(50 + n_meshes)
