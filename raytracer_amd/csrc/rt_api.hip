@@ -474,8 +474,10 @@ rt_ctx* rt_create(int device) {
     // must be dispatched between the workgroups of the long traversal kernel, not after it
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    const char* pe = std::getenv("RT_RNG_PRIO");  // tuning knob: "lo" = same priority as the traversal stream
+    const int prio_rng = (pe && pe[0] == 'l') ? prio_lo : prio_hi;
     if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_lo) != hipSuccess ||
-        hipStreamCreateWithPriority(&c->rng_stream, hipStreamNonBlocking, prio_hi) != hipSuccess) {
+        hipStreamCreateWithPriority(&c->rng_stream, hipStreamNonBlocking, prio_rng) != hipSuccess) {
         g_err = "rt_create: hipStreamCreate failed";
         return nullptr;
     }

@@ -294,7 +294,8 @@ __global__ __launch_bounds__(NT) void render_kernel(const RenderArgs a) {
         double c0 = 0.0, c1 = 0.0, c2 = 0.0;
         if (active) {
             const size_t sidx = ((size_t)py * a.W + px) * (size_t)spp + k;
-            const d2 jit = reinterpret_cast<const d2*>(a.jitter)[sidx];
+            // streamed once: non-temporal, so the 16 B/sample stream does not displace tree nodes in L2
+            const d2 jit = __builtin_nontemporal_load(reinterpret_cast<const d2*>(a.jitter) + sidx);
             // cpp/rtrender.cpp:53-58
             const double s0 = (double)px + jit.x;
             const double s1 = (double)(py + a.row0) + jit.y;
@@ -319,8 +320,8 @@ __global__ __launch_bounds__(NT) void render_kernel(const RenderArgs a) {
             trace<COUNT>(a.sc, r, stk, stride, h, n_nodes, n_tris);
             shade(a.sc, r, h, c0, c1, c2);
             if (COUNT) n_hits += (h.prim >= 0);
-            if (a.hit_prim) a.hit_prim[sidx] = h.prim;
-            if (a.hit_t) a.hit_t[sidx] = h.t;
+            if (a.hit_prim) __builtin_nontemporal_store(h.prim, a.hit_prim + sidx);
+            if (a.hit_t) __builtin_nontemporal_store(h.t, a.hit_t + sidx);
         }
         s_col[0][tid] = c0;
         s_col[1][tid] = c1;
@@ -459,6 +460,10 @@ struct PacketScene {
 #define RT_CONST __attribute__((address_space(4)))
 typedef const RT_CONST double* cdptr;
 typedef const RT_CONST uint32_t* cuptr;
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ double sgpr_f64(const u32x16& v, const int i) {
+    return __builtin_bit_cast(double, ((unsigned long long)v[2 * i + 1] << 32) | (unsigned long long)v[2 * i]);
+}
 
 struct SBox {  // wave-uniform (scalar) camera-relative box
     double mnx, mny, mnz, mxx, mxy, mxz;
@@ -545,25 +550,28 @@ __device__ __forceinline__ void trace_packet(const PacketScene& sc, const unsign
             SBox bl, br;
             uint32_t dl, dr;
             {
-                cdptr q = (cdptr)(const void*)(sc.nodes + cur);
-                bl.mnx = q[0];
-                bl.mny = q[1];
-                bl.mnz = q[2];
-                bl.mxx = q[3];
-                bl.mxy = q[4];
-                bl.mxz = q[5];
-                br.mnx = q[8];
-                br.mny = q[9];
-                br.mnz = q[10];
-                br.mxx = q[11];
-                br.mxy = q[12];
-                br.mxz = q[13];
-                cuptr m = (cuptr)(const void*)(sc.nodes + cur);
-                dl = m[15];
-                dr = m[31];
-                // keep both descriptors in the one batch of scalar loads (hipcc otherwise sinks the
-                // load of the taken child's descriptor behind the branch: a second latency per step)
-                asm volatile("" : "+s"(dl), "+s"(dr));
+                // the whole 128-byte pair as two 64-byte scalar loads (the compiler would split the fields
+                // it needs into six smaller requests; the scalar cache is a measured bottleneck)
+                u32x16 na, nb;
+                const void* np = (const void*)(sc.nodes + cur);
+                asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&s"(na), "=&s"(nb)
+                             : "s"(np)
+                             : "memory");
+                bl.mnx = sgpr_f64(na, 0);
+                bl.mny = sgpr_f64(na, 1);
+                bl.mnz = sgpr_f64(na, 2);
+                bl.mxx = sgpr_f64(na, 3);
+                bl.mxy = sgpr_f64(na, 4);
+                bl.mxz = sgpr_f64(na, 5);
+                br.mnx = sgpr_f64(nb, 0);
+                br.mny = sgpr_f64(nb, 1);
+                br.mnz = sgpr_f64(nb, 2);
+                br.mxx = sgpr_f64(nb, 3);
+                br.mxy = sgpr_f64(nb, 4);
+                br.mxz = sgpr_f64(nb, 5);
+                dl = na[15];
+                dr = nb[15];
             }
             if (COUNT) {
                 wc.nodes += 2u * (unsigned)__builtin_popcountll(inm);
@@ -571,11 +579,17 @@ __device__ __forceinline__ void trace_packet(const PacketScene& sc, const unsign
             }
             const unsigned long long ml = slab_rel<FAST, OCT>(bl, ix, iy, iz) & inm;
             const unsigned long long mr = slab_rel<FAST, OCT>(br, ix, iy, iz) & inm;
-            if (ml != 0ull) {
-                if (mr != 0ull) wstk[sp++] = make_uint4(dr, (uint32_t)mr, (uint32_t)(mr >> 32), 0u);
+            // branch flags as opaque scalar integers, one copy per use: a shared i1 would be carried
+            // between the blocks through a VGPR (v_cndmask + v_cmp per step)
+            uint32_t lnz = (uint32_t)ml | (uint32_t)(ml >> 32);
+            uint32_t rnz = (uint32_t)mr | (uint32_t)(mr >> 32);
+            uint32_t rnz2 = rnz;
+            asm volatile("" : "+s"(lnz), "+s"(rnz), "+s"(rnz2));
+            if (lnz != 0u) {
+                if (rnz != 0u) wstk[sp++] = make_uint4(dr, (uint32_t)mr, (uint32_t)(mr >> 32), 0u);
                 cur = dl;
                 inm = ml;
-            } else if (mr != 0ull) {
+            } else if (rnz2 != 0u) {
                 cur = dr;
                 inm = mr;
             } else {
@@ -742,7 +756,8 @@ __global__ __launch_bounds__(NT, 8) void render_packet_kernel(const PacketArgs a
         double dx = 0.0, dy = 0.0, dz = -1.0;
         if (active) {
             cdptr fp = (cdptr)(const void*)a.fp;  // cam[0..2] p00[3..5] sp[6..11]
-            const d2 jit = reinterpret_cast<const d2*>(a.jitter)[sidx];
+            // streamed once: non-temporal, so the 16 B/sample stream does not displace tree nodes in L2
+            const d2 jit = __builtin_nontemporal_load(reinterpret_cast<const d2*>(a.jitter) + sidx);
             // cpp/rtrender.cpp:53-58
             const double s0 = (double)px + jit.x;
             const double s1 = (double)(py + a.row0) + jit.y;
@@ -823,8 +838,8 @@ __global__ __launch_bounds__(NT, 8) void render_packet_kernel(const PacketArgs a
                 c2 = ia + al * 1.0;
             }
             if (COUNT) n_hits += (h.prim >= 0);
-            if (a.hit_prim) a.hit_prim[sidx] = h.prim;
-            if (a.hit_t) a.hit_t[sidx] = h.t;
+            if (a.hit_prim) __builtin_nontemporal_store(h.prim, a.hit_prim + sidx);
+            if (a.hit_t) __builtin_nontemporal_store(h.t, a.hit_t + sidx);
         }
         wcol[0][lane] = c0;
         wcol[1][lane] = c1;
@@ -1016,7 +1031,7 @@ __global__ __launch_bounds__(64) void mt_jitter_kernel(const uint32_t* __restric
                 const double sum = wa + wb * 4294967296.0;
                 double ret = sum / 18446744073709551616.0;
                 if (ret >= 1.0) ret = 0x1.fffffffffffffp-1;  // nextafter(1.0, 0.0)
-                out[pos + q] = ret - 0.5;
+                __builtin_nontemporal_store(ret - 0.5, out + pos + q);  // written once, read once by the next frame
             }
         }
         __builtin_amdgcn_wave_barrier();
