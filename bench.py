@@ -319,6 +319,27 @@ def main():
             t1 = time.perf_counter()
             ctx.download(intensity=False, rgb=False, hit_ids=True)
             dl_ids_ms = (time.perf_counter() - t1) * 1e3
+        # fp32 FAST PATH (RT_FLAG_FP32), reported separately with its measured tolerance against the exact
+        # f64 frame of the same samples -- never part of `value`
+        fp32 = None
+        try:
+            frame(0)
+            exact = ctx.download(rgb=False, hit_ids=want_ids)
+            f32_ms = []
+            for _ in range(3):
+                frame(0, fp32=True)
+                ctx.sync()
+                f32_ms.append(ctx.stats()["render_kernel_ms"])
+            fast = ctx.download(rgb=False, hit_ids=want_ids)
+            d = np.abs(fast["intensity"] - exact["intensity"])
+            fp32 = {"kernel_ms": float(np.mean(f32_ms[1:])),
+                    "kernel_only_mrays_s": rays_per_frame / (float(np.mean(f32_ms[1:])) * 1e-3) / 1e6,
+                    "vs_f64_exact": {"max_abs_intensity_diff": float(d.max()), "mean_abs_intensity_diff": float(d.mean()),
+                                     "hit_id_mismatch_fraction":
+                                         float((fast["hit_prim"] != exact["hit_prim"]).mean()) if want_ids else None}}
+            del exact, fast, d
+        except Exception as e:  # the fast path must never take the bench line down
+            fp32 = {"error": str(e)}
         cpu = None
         if args.cpu_rays > 0:
             frame(0)
@@ -360,7 +381,7 @@ def main():
                     "upload_s": upload_s, "stack_need": int(host.info.stack_need),
                     "download_frame_ms": dl_frame_ms, "download_hit_ids_ms": dl_ids_ms,
                     "kernel_ms_timed_step": kernel_ms[-1] if kernel_ms else None,
-                    "multiframe": multiframe},
+                    "multiframe": multiframe, "fp32_fast_path": fp32},
         }
     if dist is not None:
         dist.barrier()

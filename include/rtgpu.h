@@ -126,6 +126,9 @@ int rt_mt19937_stream_states(uint32_t seed, uint64_t base_position, uint64_t str
 #define RT_FLAG_HIT_IDS 1u  /* keep per-sample prim ids (int32, -1 = miss) */
 #define RT_FLAG_COUNTERS 2u /* count nodes/triangles visited (slower; for the roofline model) */
 #define RT_FLAG_HIT_T 4u    /* keep per-sample closest t (f64, +inf = miss) */
+#define RT_FLAG_FP32 8u     /* fp32 FAST PATH: the same frame in binary32 (north_star: "an fp32 fast path reported
+                               separately with its tolerance").  Not the parity path: hit ids may differ for rays
+                               grazing an edge, intensities are close.  No reference counterpart. */
 
 typedef struct {
     double camera_center[3];

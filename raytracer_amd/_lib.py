@@ -17,6 +17,7 @@ RT_SAMPLER_EXPLICIT = 1
 RT_FLAG_HIT_IDS = 1
 RT_FLAG_COUNTERS = 2
 RT_FLAG_HIT_T = 4
+RT_FLAG_FP32 = 8
 
 
 class RtError(RuntimeError):

@@ -134,7 +134,8 @@ class Context:
 
     # ---- render ----
     def render(self, cam, p00, spacing, H, W, spp, *, rows=None, jitter=None, hit_ids=False, hit_t=False,
-               counters=False):
+               counters=False, fp32=False):
+        """fp32=True selects the fp32 FAST PATH (RT_FLAG_FP32): not bit-exact, reported separately."""
         p = L.RenderParams()
         p.camera_center[:] = list(L.f64(cam, 3))
         p.pixel_00_center[:] = list(L.f64(p00, 3))
@@ -142,7 +143,7 @@ class Context:
         p.image_height, p.image_width, p.samples = int(H), int(W), int(spp)
         p.row_begin, p.row_end = (0, int(H)) if rows is None else (int(rows[0]), int(rows[1]))
         p.flags = (L.RT_FLAG_HIT_IDS if hit_ids else 0) | (L.RT_FLAG_HIT_T if hit_t else 0) | (
-            L.RT_FLAG_COUNTERS if counters else 0)
+            L.RT_FLAG_COUNTERS if counters else 0) | (L.RT_FLAG_FP32 if fp32 else 0)
         keep = None
         if jitter is not None:
             keep = L.f64(jitter).reshape(-1)

@@ -19,6 +19,7 @@
 #include "../../include/rtgpu.h"
 #include "rt_bvh.hpp"
 #include "rt_kernels.hip.hpp"
+#include "rt_kernels_fp32.hip.hpp"
 #include "rt_mt19937.hpp"
 
 struct rt_scene {
@@ -96,6 +97,10 @@ struct rt_ctx {
     // camera-relative copies for the packet kernel (rebuilt per render by the prep kernels)
     DevBuf<rt::DevNode> cam_nodes, cam_tlas;
     DevBuf<rtk::CamTri> cam_tris;
+    // fp32 fast path records (RT_FLAG_FP32), allocated on first use
+    DevBuf<rtk32::Node32> nodes32;
+    DevBuf<rtk32::Tlas32> tlas32;
+    DevBuf<rtk32::Tri32> tris32;
     DevBuf<rtk::FrameParams> frame_params;
     rtk::FrameParams h_frame_params;  // host copy kept alive for the async upload
     size_t n_nodes = 0, n_tlas = 0;
@@ -522,6 +527,9 @@ void rt_destroy(rt_ctx* c) {
     c->cam_nodes.release();
     c->cam_tlas.release();
     c->cam_tris.release();
+    c->nodes32.release();
+    c->tlas32.release();
+    c->tris32.release();
     c->frame_params.release();
     c->d_states.release();
     c->jitter.release();
@@ -754,8 +762,60 @@ int rt_render(rt_ctx* c, const rt_render_params* p) {
     if (n_tiles > 0x7fffffff) return fail(RT_E_LIMIT, "rt_render: too many tiles");
     const bool count = (p->flags & RT_FLAG_COUNTERS) != 0;
     if (count) HIP_TRY(hipMemsetAsync(c->counters.p, 0, 4 * sizeof(unsigned long long), c->stream));
-    const bool packet = c->stack_need <= rtk::PACKET_STACK && !force_per_lane();
-    if (packet) {
+    // the packet kernels address nodes with a 32-bit scalar byte offset: node array < 4 GB (6.7e7 nodes)
+    const bool packet = c->stack_need <= rtk::PACKET_STACK && !force_per_lane() && c->n_nodes < (size_t(1) << 26);
+    if (p->flags & RT_FLAG_FP32) {
+        // fp32 FAST PATH (not the parity path): same walk in binary32, see rt_kernels_fp32.hip.hpp
+        if (c->stack_need > rtk::PACKET_STACK || c->n_nodes >= (size_t(1) << 26))
+            return fail(RT_E_LIMIT, "rt_render: RT_FLAG_FP32 needs a traversal stack <= 128 entries and < 2^26 nodes");
+        if ((rc = c->nodes32.ensure(c->n_nodes))) return rc;
+        if ((rc = c->tlas32.ensure(c->n_tlas))) return rc;
+        if ((rc = c->tris32.ensure((size_t)c->n_tris))) return rc;
+        const double ox = p->camera_center[0], oy = p->camera_center[1], oz = p->camera_center[2];
+        hipLaunchKernelGGL(rtk32::prep32_nodes_kernel, dim3((unsigned)((c->n_nodes + 255) / 256)), dim3(256), 0,
+                           c->stream, c->nodes.p, c->nodes32.p, (long long)c->n_nodes, ox, oy, oz);
+        hipLaunchKernelGGL(rtk32::prep32_tlas_kernel, dim3((unsigned)((c->n_tlas + 255) / 256)), dim3(256), 0, c->stream,
+                           c->tlas.p, c->tlas32.p, (long long)c->n_tlas, ox, oy, oz);
+        hipLaunchKernelGGL(rtk32::prep32_tris_kernel, dim3((unsigned)((c->n_tris + 255) / 256)), dim3(256), 0, c->stream,
+                           c->tris.p, c->tris32.p, (long long)c->n_tris, ox, oy, oz);
+        HIP_TRY(hipGetLastError());
+        if ((rc = c->frame_params.ensure(1))) return rc;
+        for (int i = 0; i < 3; ++i) {
+            c->h_frame_params.cam[i] = p->camera_center[i];
+            c->h_frame_params.p00[i] = p->pixel_00_center[i];
+        }
+        for (int i = 0; i < 6; ++i) c->h_frame_params.sp[i] = p->pixel_spacing[i];
+        HIP_TRY(hipMemcpyAsync(c->frame_params.p, &c->h_frame_params, sizeof(rtk::FrameParams), hipMemcpyHostToDevice,
+                               c->stream));
+        rtk32::Packet32Args a;
+        a.nodes = c->nodes32.p;
+        a.tlas = c->tlas32.p;
+        a.slot_root = c->slot_root.p;
+        a.leaf_ext = c->leaf_ext.p;
+        a.tris = c->tris32.p;
+        a.colors = c->colors.p;
+        a.fp = c->frame_params.p;
+        a.W = W;
+        a.spp = spp;
+        a.row0 = p->row_begin;
+        a.rows = rows;
+        a.tile_log2 = tile_log2;
+        a.tiles_x = tiles_x;
+        a.n_tiles = (int32_t)n_tiles;
+        a.jitter = d_jitter;
+        a.intensity = c->intensity.p;
+        a.rgb = c->rgb.p;
+        a.hit_prim = (p->flags & RT_FLAG_HIT_IDS) ? c->hit_prim.p : nullptr;
+        a.hit_t = (p->flags & RT_FLAG_HIT_T) ? c->hit_t.p : nullptr;
+        a.counters = count ? c->counters.p : nullptr;
+        HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+        if (count)
+            hipLaunchKernelGGL(rtk32::render_packet32_kernel<true>, dim3((unsigned)n_tiles), dim3(rtk::NT), 0, c->stream, a);
+        else
+            hipLaunchKernelGGL(rtk32::render_packet32_kernel<false>, dim3((unsigned)n_tiles), dim3(rtk::NT), 0, c->stream, a);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    } else if (packet) {
         // Wave-packet traversal on camera-relative records (see rt_kernels.hip.hpp).
         const double ox = p->camera_center[0], oy = p->camera_center[1], oz = p->camera_center[2];
         hipLaunchKernelGGL(rtk::prep_nodes_kernel, dim3((unsigned)((c->n_nodes + 255) / 256)), dim3(256), 0, c->stream,

@@ -49,6 +49,7 @@ constexpr uint32_t DESC_LEAF = 0x80000000u;
 constexpr uint32_t DESC_TLAS = 0x40000000u;
 constexpr uint32_t DESC_ROOT = 0x20000000u;
 constexpr uint32_t DESC_TRI_MASK = 0x0FFFFFFFu;
+constexpr uint32_t DESC_NONE = 0xFFFFFFFFu;  // never a real descriptor (< 2^28 - 1 triangles / leaf_ext slots): "no node"
 constexpr int64_t MAX_DEV_NODES = (1ll << 29) - 2;
 constexpr int64_t MAX_TRIS = (1ll << 28) - 1;
 

@@ -543,21 +543,23 @@ __device__ __forceinline__ void trace_packet(const PacketScene& sc, const unsign
     unsigned long long inm = valid_mask;
     for (;;) {
         // ---- descend through internal BLAS nodes (the hot loop) ----
-        bool alive = true;
+        // One straight-line body with a single back edge: the scalar unit issues as slowly as the fp64
+        // VALU (one instruction per SIMD every 4 cycles), so SALU instructions count like VALU ones.
+        // The next node / mask are scalar selects; `cur = DESC_NONE` when no lane hit either child.
         while ((cur & (rt::DESC_LEAF | rt::DESC_TLAS | rt::DESC_ROOT)) == 0u) {
-            // both children in one 128-byte scalar fetch, tested unconditionally (lanes outside
-            // `inm` compute garbage that the mask discards)
+            // both children: the whole 128-byte pair as two 64-byte scalar loads at base + (cur << 6)
+            // (host guarantees the node array is < 4 GB), tested unconditionally -- lanes outside `inm`
+            // compute garbage that the mask discards
             SBox bl, br;
             uint32_t dl, dr;
             {
-                // the whole 128-byte pair as two 64-byte scalar loads (the compiler would split the fields
-                // it needs into six smaller requests; the scalar cache is a measured bottleneck)
                 u32x16 na, nb;
-                const void* np = (const void*)(sc.nodes + cur);
-                asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)"
-                             : "=&s"(na), "=&s"(nb)
-                             : "s"(np)
-                             : "memory");
+                const uint32_t off = cur << 6;
+                asm volatile(
+                    "s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx16 %1, %2, %3 offset:0x40\n\ts_waitcnt lgkmcnt(0)"
+                    : "=&s"(na), "=&s"(nb)
+                    : "s"(sc.nodes), "s"(off)
+                    : "memory");
                 bl.mnx = sgpr_f64(na, 0);
                 bl.mny = sgpr_f64(na, 1);
                 bl.mnz = sgpr_f64(na, 2);
@@ -579,24 +581,17 @@ __device__ __forceinline__ void trace_packet(const PacketScene& sc, const unsign
             }
             const unsigned long long ml = slab_rel<FAST, OCT>(bl, ix, iy, iz) & inm;
             const unsigned long long mr = slab_rel<FAST, OCT>(br, ix, iy, iz) & inm;
-            // branch flags as opaque scalar integers, one copy per use: a shared i1 would be carried
-            // between the blocks through a VGPR (v_cndmask + v_cmp per step)
+            // flags as opaque scalar integers (a shared i1 would travel through a VGPR)
             uint32_t lnz = (uint32_t)ml | (uint32_t)(ml >> 32);
             uint32_t rnz = (uint32_t)mr | (uint32_t)(mr >> 32);
-            uint32_t rnz2 = rnz;
-            asm volatile("" : "+s"(lnz), "+s"(rnz), "+s"(rnz2));
-            if (lnz != 0u) {
-                if (rnz != 0u) wstk[sp++] = make_uint4(dr, (uint32_t)mr, (uint32_t)(mr >> 32), 0u);
-                cur = dl;
-                inm = ml;
-            } else if (rnz2 != 0u) {
-                cur = dr;
-                inm = mr;
-            } else {
-                alive = false;
-                break;
-            }
+            uint32_t both = lnz < rnz ? lnz : rnz;  // s_min_u32: non-zero iff both are
+            asm volatile("" : "+s"(lnz), "+s"(rnz), "+s"(both));
+            if (both != 0u) wstk[sp++] = make_uint4(dr, (uint32_t)mr, (uint32_t)(mr >> 32), 0u);
+            uint32_t nxt = (lnz != 0u) ? dl : dr;
+            inm = (lnz != 0u) ? ml : mr;
+            cur = ((lnz | rnz) != 0u) ? nxt : rt::DESC_NONE;
         }
+        const bool alive = cur != rt::DESC_NONE;
         if (alive) {
             if (cur & rt::DESC_LEAF) {
                 uint32_t first = cur & rt::DESC_TRI_MASK;
@@ -743,21 +738,41 @@ __global__ __launch_bounds__(NT, 8) void render_packet_kernel(const PacketArgs a
     unsigned long long w_nodes = 0, w_tris = 0, w_steps = 0;  // lane 0 of each wave carries the wave's sums
     uint32_t n_hits = 0;
 
-    for (int base = 0; base < n_rays; base += 64) {
+    // The jitter pair of the NEXT batch is requested before this batch is traversed (one HBM round trip
+    // off every batch's critical path: the kernel is bound by per-wave latency at 8 waves per SIMD).
+    struct Slot {
+        int px, py;
+        bool active;
+        size_t sidx;
+        d2 jit;
+    };
+    auto fetch = [&](const int base) {
+        Slot q;
         const int rr = base + lane;
         const int ml = rr / spp;
         const int k = rr - ml * spp;
         const int m = m0 + ml;
-        const int px = tx0 + (int)compact1by1((uint32_t)m);
-        const int py = ty0 + (int)compact1by1((uint32_t)m >> 1);
-        const bool active = (rr < n_rays) && (px < a.W) && (py < a.rows);
+        q.px = tx0 + (int)compact1by1((uint32_t)m);
+        q.py = ty0 + (int)compact1by1((uint32_t)m >> 1);
+        q.active = (rr < n_rays) && (q.px < a.W) && (q.py < a.rows);
+        q.sidx = q.active ? ((size_t)q.py * a.W + q.px) * (size_t)spp + k : 0;
+        q.jit = d2{0.0, 0.0};
+        // streamed once: non-temporal, so the 16 B/sample stream does not displace tree nodes in L2
+        if (q.active) q.jit = __builtin_nontemporal_load(reinterpret_cast<const d2*>(a.jitter) + q.sidx);
+        return q;
+    };
+    Slot nxt = fetch(0);
+    for (int base = 0; base < n_rays; base += 64) {
+        const Slot cs = nxt;
+        if (base + 64 < n_rays) nxt = fetch(base + 64);
+        const int px = cs.px, py = cs.py;
+        const bool active = cs.active;
+        const size_t sidx = cs.sidx;
         double c0 = 0.0, c1 = 0.0, c2 = 0.0;
-        const size_t sidx = active ? ((size_t)py * a.W + px) * (size_t)spp + k : 0;
         double dx = 0.0, dy = 0.0, dz = -1.0;
         if (active) {
             cdptr fp = (cdptr)(const void*)a.fp;  // cam[0..2] p00[3..5] sp[6..11]
-            // streamed once: non-temporal, so the 16 B/sample stream does not displace tree nodes in L2
-            const d2 jit = __builtin_nontemporal_load(reinterpret_cast<const d2*>(a.jitter) + sidx);
+            const d2 jit = cs.jit;
             // cpp/rtrender.cpp:53-58
             const double s0 = (double)px + jit.x;
             const double s1 = (double)(py + a.row0) + jit.y;
@@ -860,15 +875,12 @@ __global__ __launch_bounds__(NT, 8) void render_packet_kernel(const PacketArgs a
                 const double* src = &wcol[c][lo];
                 const int n = hi - lo;
                 int s2 = 0;
-                for (; s2 + 8 <= n; s2 += 8) {  // strictly in sample order; unrolled for LDS immediates
-                    acc += src[s2];
-                    acc += src[s2 + 1];
-                    acc += src[s2 + 2];
-                    acc += src[s2 + 3];
-                    acc += src[s2 + 4];
-                    acc += src[s2 + 5];
-                    acc += src[s2 + 6];
-                    acc += src[s2 + 7];
+                for (; s2 + 8 <= n; s2 += 8) {  // strictly in sample order; the 8 LDS reads are issued
+                    double v8[8];                 // together, ahead of the dependent adds
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v8[j] = src[s2 + j];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc += v8[j];
                 }
                 for (; s2 < n; ++s2) acc += src[s2];
                 wacc[c][pm] = acc;
