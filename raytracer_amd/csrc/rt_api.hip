@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <future>
 #include <map>
 #include <memory>
@@ -1082,7 +1083,7 @@ int rt_render_scene(int image_height, int image_width, int number_of_samples, co
 
     const uint64_t frame_words = uint64_t(image_height) * uint64_t(image_width) * uint64_t(number_of_samples) * 4u;
     const uint64_t base = rt_rng_tell(c);
-    std::vector<uint8_t> rgb(size_t(image_height) * size_t(image_width) * 3);
+    const size_t rgb_bytes = size_t(image_height) * size_t(image_width) * 3;
     int rc = RT_OK;
     const int64_t n_mine = rt_shard_frames(timestep_count, n_cameras, rank, world, base, frame_words, 0, nullptr, nullptr);
     std::vector<int64_t> my_frames((size_t)std::max<int64_t>(n_mine, 1));
@@ -1107,33 +1108,58 @@ int rt_render_scene(int image_height, int image_width, int number_of_samples, co
             return b;
         });
     };
-    std::future<Built> pending;
+    // RT_DRIVER_TIMING=1: per-phase wall time of this call on stderr (tuning aid)
+    const bool timing = std::getenv("RT_DRIVER_TIMING") != nullptr;
+    double t_wait = 0, t_upload = 0, t_render = 0, t_down = 0, t_write = 0;
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    // Builds run ahead of the GPU on helper threads: up to `depth` timesteps in flight (each build is
+    // itself parallel over meshes), fewer for big scenes whose flattened copies are large.
+    int64_t tris_per_step = 0;
+    for (int m = 0; m < n_meshes; ++m) tris_per_step += elem_counts[m];
+    size_t depth = tris_per_step > 4000000 ? 1 : (tris_per_step > 500000 ? 2 : 3);
+    if (const char* e = std::getenv("RT_BUILD_AHEAD")) depth = (size_t)std::max(1, std::atoi(e));
+    std::deque<std::future<Built>> pending;
     size_t next_step = 0;
-    if (!my_steps.empty()) pending = build_async(my_steps[next_step++]);
+    auto top_up = [&]() {
+        while (pending.size() < depth && next_step < my_steps.size()) pending.push_back(build_async(my_steps[next_step++]));
+    };
+    auto drain = [&]() {
+        for (auto& f : pending) rt_scene_free(f.get().sc);
+        pending.clear();
+    };
+    // P6 files are written by a helper thread while the next frame renders (two host frame buffers)
+    std::vector<uint8_t> rgb2[2] = {std::vector<uint8_t>(rgb_bytes), std::vector<uint8_t>(rgb_bytes)};
+    std::future<void> writer;
+    int wbuf = 0;
+    top_up();
     int built_t = -1;
     for (int64_t q = 0; q < n_mine; ++q) {
         const int t = (int)(my_frames[q] / n_cameras), cam = (int)(my_frames[q] % n_cameras);
+        auto bail = [&](int code) {
+            drain();
+            if (writer.valid()) writer.get();
+            return code;
+        };
         if (t != built_t) {  // frames arrive timestep-major: one build per timestep this rank touches
-            Built b = pending.get();
-            if (next_step < my_steps.size()) pending = build_async(my_steps[next_step++]);
+            double t0 = now();
+            Built b = pending.front().get();
+            pending.pop_front();
+            t_wait += now() - t0;
+            top_up();
             if (!b.sc) {
-                if (pending.valid()) rt_scene_free(pending.get().sc);
-                return fail(RT_E_INVALID, b.err);
+                const std::string msg = b.err;
+                bail(0);
+                return fail(RT_E_INVALID, msg);
             }
             for (int64_t k = 0; k < b.sc->s->midpoint_fallbacks; ++k)
                 std::printf("SAH splitting failed. Trying midpoint instead.\n");  // cpp/rtbvh.cpp:128
+            t0 = now();
             rc = rt_upload_scene(c, b.sc);
+            t_upload += now() - t0;
             rt_scene_free(b.sc);
-            if (rc) {
-                if (pending.valid()) rt_scene_free(pending.get().sc);
-                return rc;
-            }
+            if (rc) return bail(rc);
             built_t = t;
         }
-        auto bail = [&](int code) {
-            if (pending.valid()) rt_scene_free(pending.get().sc);
-            return code;
-        };
         if ((rc = rt_rng_seek(c, my_pos[q]))) return bail(rc);
         std::printf("Rendering frame %d/%d\n", t + 1, timestep_count);  // cpp/rtmain.cpp:61
         std::fflush(stdout);
@@ -1148,14 +1174,30 @@ int rt_render_scene(int image_height, int image_width, int number_of_samples, co
         p.row_begin = 0;
         p.row_end = image_height;
         p.sampler = RT_SAMPLER_MT19937;
+        double t1 = now();
         if ((rc = rt_render(c, &p))) return bail(rc);
-        if ((rc = rt_download(c, nullptr, rgb.data(), nullptr, nullptr))) return bail(rc);
+        t_render += now() - t1;
+        t1 = now();
+        if (writer.valid()) writer.get();  // previous file done (it was being written while this frame rendered)
+        uint8_t* dst = rgb2[wbuf].data();
+        if ((rc = rt_download(c, nullptr, dst, nullptr, nullptr))) return bail(rc);
+        t_down += now() - t1;
+        t1 = now();
         // cpp/rtmain.cpp:58-60: rtimage_<timestep>_cam<camera>.ppm, zero-based
         std::string path = std::string(output_directory) + "/rtimage_" + std::to_string(t) + "_cam" +
                            std::to_string(cam) + ".ppm";
         // like the reference, an unopenable file is reported and the job goes on
-        (void)rt_write_ppm(path.c_str(), image_width, image_height, rgb.data());
+        writer = std::async(std::launch::async, [path, image_width, image_height, dst]() {
+            (void)rt_write_ppm(path.c_str(), image_width, image_height, dst);
+        });
+        wbuf ^= 1;
+        t_write += now() - t1;
     }
+    if (writer.valid()) writer.get();
+    if (timing)
+        std::fprintf(stderr, "rt_render_scene: %lld frames: wait-for-build %.1f ms, upload %.1f, render-call %.1f, "
+                             "download(sync) %.1f, ppm %.1f\n",
+                     (long long)n_mine, t_wait * 1e3, t_upload * 1e3, t_render * 1e3, t_down * 1e3, t_write * 1e3);
     // every rank leaves the global stream where the unsharded job would have left it
     return rt_rng_seek(c, base + uint64_t(timestep_count) * uint64_t(n_cameras) * frame_words);
 }

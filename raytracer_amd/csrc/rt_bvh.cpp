@@ -18,8 +18,15 @@
 #include "rt_bvh.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <memory>
@@ -73,10 +80,141 @@ struct Elements {
     const Box* box;
 };
 
+// ---------------------------------------------------------------------------------------
+// Host parallelism.  A small persistent pool; parallel_for's caller takes part in its own job and
+// only ever waits for chunks that some thread is already running, so nested and concurrent calls
+// (one build per mesh, several timesteps in flight) cannot deadlock.  Every parallel pass below
+// merges its per-chunk partial results IN CHUNK ORDER with the same `(p < m) ? p : m` rule the
+// serial loop uses, so the outcome is bit-identical to the serial pass (first occurrence wins
+// among equal values, which also fixes the sign of a zero) whatever the thread count.
+// ---------------------------------------------------------------------------------------
+int pool_threads() {
+    const char* e = std::getenv("RT_HOST_THREADS");
+    int n = e ? std::atoi(e) : 0;
+    if (n <= 0) {
+        const char* omp = std::getenv("OMP_NUM_THREADS");
+        n = omp ? std::atoi(omp) : 0;
+    }
+    if (n <= 0) n = static_cast<int>(std::thread::hardware_concurrency());
+    return std::max(1, std::min(n, 16));
+}
+
+class Pool {
+public:
+    static Pool& get() {
+        static Pool p(pool_threads() - 1);
+        return p;
+    }
+    int width() const { return static_cast<int>(workers_.size()) + 1; }
+    void parallel_for(int64_t n, const std::function<void(int64_t)>& fn) {
+        if (n <= 0) return;
+        if (n == 1 || workers_.empty()) {
+            for (int64_t i = 0; i < n; ++i) fn(i);
+            return;
+        }
+        auto job = std::make_shared<Job>();
+        job->n = n;
+        job->fn = &fn;
+        const int64_t helpers = std::min<int64_t>(n - 1, static_cast<int64_t>(workers_.size()));
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            for (int64_t h = 0; h < helpers; ++h) queue_.push_back(job);
+        }
+        cv_.notify_all();
+        run(*job);
+        std::unique_lock<std::mutex> lk(job->mu);
+        job->cv.wait(lk, [&] { return job->done.load() == job->n; });
+        if (!job->error.empty()) throw std::runtime_error(job->error);
+    }
+
+private:
+    struct Job {
+        int64_t n = 0;
+        const std::function<void(int64_t)>* fn = nullptr;  // valid until done == n (the caller waits)
+        std::atomic<int64_t> next{0}, done{0};
+        std::mutex mu;
+        std::condition_variable cv;
+        std::string error;
+    };
+    static void run(Job& j) {
+        for (;;) {
+            const int64_t i = j.next.fetch_add(1);
+            if (i >= j.n) return;
+            try {
+                (*j.fn)(i);
+            } catch (const std::exception& e) {
+                std::lock_guard<std::mutex> lk(j.mu);
+                j.error = e.what();
+            }
+            if (j.done.fetch_add(1) + 1 == j.n) {
+                std::lock_guard<std::mutex> lk(j.mu);
+                j.cv.notify_all();
+            }
+        }
+    }
+    explicit Pool(int n) {
+        for (int i = 0; i < n; ++i)
+            workers_.emplace_back([this] {
+                for (;;) {
+                    std::shared_ptr<Job> job;
+                    {
+                        std::unique_lock<std::mutex> lk(mu_);
+                        cv_.wait(lk, [&] { return stop_ || !queue_.empty(); });
+                        if (stop_ && queue_.empty()) return;
+                        job = queue_.front();
+                        queue_.pop_front();
+                    }
+                    if (job->next.load() < job->n) run(*job);
+                }
+            });
+    }
+    ~Pool() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto& t : workers_) t.join();
+    }
+    std::vector<std::thread> workers_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::deque<std::shared_ptr<Job>> queue_;
+    bool stop_ = false;
+};
+
+constexpr int64_t kParMin = 1 << 16;    // ranges at least this long are scanned by several threads
+constexpr int64_t kParChunk = 1 << 14;  // elements per chunk of such a scan
+
+// fn(chunk, lo, hi) over [first, first+count) in chunks; serial (one chunk) for short ranges
+template <class F>
+void for_chunks(int64_t first, int64_t count, int64_t& n_chunks, const F& fn) {
+    if (count < kParMin) {
+        n_chunks = 1;
+        fn(0, first, first + count);
+        return;
+    }
+    n_chunks = (count + kParChunk - 1) / kParChunk;
+    const int64_t nc = n_chunks;
+    Pool::get().parallel_for(nc, [&](int64_t c) {
+        const int64_t lo = first + c * kParChunk;
+        fn(c, lo, std::min(first + count, lo + kParChunk));
+    });
+}
+
 Box range_box(const Elements& el, const int32_t* idx, int64_t first, int64_t count) {
+    const int64_t max_chunks = count < kParMin ? 1 : (count + kParChunk - 1) / kParChunk;
+    std::vector<Box> part(static_cast<size_t>(max_chunks));
+    int64_t nc = 0;
+    for_chunks(first, count, nc, [&](int64_t c, int64_t lo, int64_t hi) {
+        Box b;
+        b.reset();
+        for (int64_t i = lo; i < hi; ++i) b.add_box(el.box[idx[i]]);
+        part[c] = b;
+    });
     Box b;
     b.reset();
-    for (int64_t i = first; i < first + count; ++i) b.add_box(el.box[idx[i]]);
+    for (int64_t c = 0; c < nc; ++c) b.add_box(part[c]);
     return b;
 }
 
@@ -86,7 +224,18 @@ bool choose_split(const Elements& el, const int32_t* idx, int64_t first, int64_t
     if (count <= 2) return false;
     Box cb;
     cb.reset();
-    for (int64_t i = first; i < first + count; ++i) cb.add_point(el.cent[idx[i]].c);
+    {
+        const int64_t max_chunks = count < kParMin ? 1 : (count + kParChunk - 1) / kParChunk;
+        std::vector<Box> part(static_cast<size_t>(max_chunks));
+        int64_t nc = 0;
+        for_chunks(first, count, nc, [&](int64_t c, int64_t lo, int64_t hi) {
+            Box b;
+            b.reset();
+            for (int64_t i = lo; i < hi; ++i) b.add_point(el.cent[idx[i]].c);
+            part[c] = b;
+        });
+        for (int64_t c = 0; c < nc; ++c) cb.add_box(part[c]);
+    }
 
     int axis = 0;
     double ext = cb.extent(0);
@@ -112,13 +261,35 @@ bool choose_split(const Elements& el, const int32_t* idx, int64_t first, int64_t
     }
     const double inv_ext = 1.0 / ext;
     const double cmin = cb.mn[axis];
-    for (int64_t i = first; i < first + count; ++i) {
-        const int32_t e = idx[i];
-        double t = (el.cent[e].c[axis] - cmin) * inv_ext;
-        int b = static_cast<int>(t * kBins);
-        if (b == kBins) b = kBins - 1;
-        bin_cnt[b]++;
-        bin_box[b].add_box(el.box[e]);
+    {
+        struct Bins {
+            Box box[kBins];
+            uint32_t cnt[kBins];
+        };
+        const int64_t max_chunks = count < kParMin ? 1 : (count + kParChunk - 1) / kParChunk;
+        std::vector<Bins> part(static_cast<size_t>(max_chunks));
+        int64_t nc = 0;
+        for_chunks(first, count, nc, [&](int64_t c, int64_t lo, int64_t hi) {
+            Bins& p = part[c];
+            for (int b = 0; b < kBins; ++b) {
+                p.box[b].reset();
+                p.cnt[b] = 0;
+            }
+            for (int64_t i = lo; i < hi; ++i) {
+                const int32_t e = idx[i];
+                double t = (el.cent[e].c[axis] - cmin) * inv_ext;
+                int b = static_cast<int>(t * kBins);
+                if (b == kBins) b = kBins - 1;
+                p.cnt[b]++;
+                p.box[b].add_box(el.box[e]);
+            }
+        });
+        for (int64_t c = 0; c < nc; ++c)
+            for (int b = 0; b < kBins; ++b) {
+                if (part[c].cnt[b] == 0) continue;
+                bin_cnt[b] += part[c].cnt[b];
+                bin_box[b].add_box(part[c].box[b]);
+            }
     }
 
     uint32_t lcnt[kBins], rcnt[kBins];
@@ -202,24 +373,28 @@ Box get_box(const HostNode& n) {
     return b;
 }
 
-// Shared stack builder (BLAS: max_leaf 4, TLAS: max_leaf 2).
-void build_tree(std::vector<HostNode>& nodes, const Elements& el, int32_t* idx, int64_t n_elem, int max_leaf,
-                int64_t& fallbacks) {
-    nodes.clear();
-    nodes.reserve(static_cast<size_t>(n_elem) * 2 / std::max(1, max_leaf - 1) + 8);
-    HostNode root{};
-    set_box(root, range_box(el, idx, 0, n_elem));
-    root.count = n_elem;
-    root.left = -1;
-    root.first = 0;
-    nodes.push_back(root);
+// Serial stack builder (BLAS: max_leaf 4, TLAS: max_leaf 2): the reference's loop.  nodes[0] must be
+// the root (box, count, first set, left = -1); descendants are appended in the reference's order.
+// `defer_below` > 0: a node with max_leaf < count <= defer_below is not expanded but recorded in
+// `deferred` together with the index its first descendant would have received.
+struct Deferred {
+    int32_t node;        // provisional index of the subtree root
+    int64_t first, count;
+    int64_t insert_pos;  // nodes.size() when the root was popped
+};
 
+void expand(std::vector<HostNode>& nodes, const Elements& el, int32_t* idx, int max_leaf, int64_t& fallbacks,
+            int64_t defer_below, std::vector<Deferred>* deferred) {
     std::vector<Task> stack;
-    stack.push_back({n_elem, 0, 0});
+    stack.push_back({nodes[0].count, 0, nodes[0].first});
     while (!stack.empty()) {
         const Task t = stack.back();
         stack.pop_back();
         if (t.count <= max_leaf) continue;  // node already carries count / box / first / left = -1
+        if (deferred && t.count <= defer_below) {
+            deferred->push_back({t.node, t.first, t.count, static_cast<int64_t>(nodes.size())});
+            continue;
+        }
         const Box parent = get_box(nodes[t.node]);
         const int64_t nl = partition(el, idx, t.first, t.count, parent, fallbacks);
         if (nl < 0) continue;  // stays a leaf with t.count elements (possibly > max_leaf)
@@ -245,17 +420,107 @@ void build_tree(std::vector<HostNode>& nodes, const Elements& el, int32_t* idx, 
     }
 }
 
+// Tree over idx[0, n_elem).  Large inputs: the top of the tree is expanded by one thread (its long
+// scans are themselves chunk-parallel), subtrees of <= n/64 elements are built concurrently on
+// disjoint ranges of idx, each with LOCAL node numbers, and spliced in at the positions the serial
+// loop would have given them: the loop numbers a node's descendants contiguously from the moment
+// the node is popped, so a subtree's block starts at its insert_pos plus the sizes of the blocks
+// spliced in before it.  The result is identical to the serial build, node for node.
+void build_tree(std::vector<HostNode>& nodes, const Elements& el, int32_t* idx, int64_t n_elem, int max_leaf,
+                int64_t& fallbacks) {
+    nodes.clear();
+    HostNode root{};
+    set_box(root, range_box(el, idx, 0, n_elem));
+    root.count = n_elem;
+    root.left = -1;
+    root.first = 0;
+    if (n_elem < 2 * kParMin || Pool::get().width() == 1) {
+        nodes.reserve(static_cast<size_t>(n_elem) * 2 / std::max(1, max_leaf - 1) + 8);
+        nodes.push_back(root);
+        expand(nodes, el, idx, max_leaf, fallbacks, 0, nullptr);
+        return;
+    }
+    std::vector<HostNode> top;
+    top.push_back(root);
+    std::vector<Deferred> deferred;
+    expand(top, el, idx, max_leaf, fallbacks, std::max<int64_t>(4096, n_elem / 64), &deferred);
+
+    const int64_t nd = static_cast<int64_t>(deferred.size());
+    std::vector<std::vector<HostNode>> sub(static_cast<size_t>(nd));
+    std::vector<int64_t> sub_fallbacks(static_cast<size_t>(nd), 0);
+    Pool::get().parallel_for(nd, [&](int64_t i) {
+        const Deferred& d = deferred[i];
+        std::vector<HostNode>& v = sub[i];
+        v.reserve(static_cast<size_t>(d.count) * 2 / std::max(1, max_leaf - 1) + 8);
+        v.push_back(top[d.node]);  // local root (index 0); descendants get local indices 1, 2, ...
+        expand(v, el, idx, max_leaf, sub_fallbacks[i], 0, nullptr);
+    });
+
+    // splice
+    std::vector<int64_t> block_start(static_cast<size_t>(nd));
+    int64_t extra = 0;
+    for (int64_t i = 0; i < nd; ++i) {
+        block_start[i] = deferred[i].insert_pos + extra;
+        extra += static_cast<int64_t>(sub[i].size()) - 1;
+        fallbacks += sub_fallbacks[i];
+    }
+    const int64_t total = static_cast<int64_t>(top.size()) + extra;
+    if (total > static_cast<int64_t>(std::numeric_limits<int32_t>::max()))
+        throw std::runtime_error("BVH has more than 2^31 nodes");
+    nodes.resize(static_cast<size_t>(total));
+    // provisional index p -> p + sizes of the blocks inserted at or before p
+    std::vector<int64_t> shift_at(top.size() + 1, 0);
+    {
+        int64_t d = 0, acc = 0;
+        for (size_t p = 0; p <= top.size(); ++p) {
+            while (d < nd && deferred[d].insert_pos <= static_cast<int64_t>(p)) {
+                acc += static_cast<int64_t>(sub[d].size()) - 1;
+                ++d;
+            }
+            shift_at[p] = acc;
+        }
+    }
+    for (size_t p = 0; p < top.size(); ++p) {
+        HostNode n = top[p];
+        if (n.left >= 0) n.left = static_cast<int32_t>(n.left + shift_at[n.left]);
+        nodes[p + shift_at[p]] = n;
+    }
+    Pool::get().parallel_for(nd, [&](int64_t i) {
+        const std::vector<HostNode>& v = sub[i];
+        const int64_t base = block_start[i] - 1;  // local index L >= 1  ->  base + L
+        HostNode& r = nodes[deferred[i].node + shift_at[deferred[i].node]];
+        r = v[0];
+        if (r.left >= 0) r.left = static_cast<int32_t>(base + r.left);
+        for (size_t L = 1; L < v.size(); ++L) {
+            HostNode n = v[L];
+            if (n.left >= 0) n.left = static_cast<int32_t>(base + n.left);
+            nodes[base + static_cast<int64_t>(L)] = n;
+        }
+    });
+}
+
 void build_one_blas(HostBlas& b, int32_t mesh, const double* coords_t, int64_t E, Centroid& mesh_cent) {
     std::vector<Centroid> cent(static_cast<size_t>(E));
     std::vector<Box> boxes(static_cast<size_t>(E));
     Box mesh_box;
     mesh_box.reset();
-    for (int64_t e = 0; e < E; ++e) {
-        const double* tc = coords_t + e * 9;
-        for (int i = 0; i < 3; ++i) cent[e].c[i] = (tc[i] + tc[i + 3] + tc[i + 6]) / 3.0;
-        boxes[e].reset();
-        for (int v = 0; v < 3; ++v) boxes[e].add_point(tc + 3 * v);
-        mesh_box.add_box(boxes[e]);
+    {
+        const int64_t max_chunks = E < kParMin ? 1 : (E + kParChunk - 1) / kParChunk;
+        std::vector<Box> part(static_cast<size_t>(max_chunks));
+        int64_t nc = 0;
+        for_chunks(0, E, nc, [&](int64_t c, int64_t lo, int64_t hi) {
+            Box mb;
+            mb.reset();
+            for (int64_t e = lo; e < hi; ++e) {
+                const double* tc = coords_t + e * 9;
+                for (int i = 0; i < 3; ++i) cent[e].c[i] = (tc[i] + tc[i + 3] + tc[i + 6]) / 3.0;
+                boxes[e].reset();
+                for (int v = 0; v < 3; ++v) boxes[e].add_point(tc + 3 * v);
+                mb.add_box(boxes[e]);
+            }
+            part[c] = mb;
+        });
+        for (int64_t c = 0; c < nc; ++c) mesh_box.add_box(part[c]);
     }
     for (int i = 0; i < 3; ++i) mesh_cent.c[i] = (mesh_box.mn[i] + mesh_box.mx[i]) / 2.0;
     std::memcpy(b.mn, mesh_box.mn, sizeof(b.mn));
@@ -322,6 +587,7 @@ Scene* build_scene(int n_meshes, const double* const* coords, const double* cons
             if (!e.empty()) throw std::runtime_error(e);
     }
 
+    const double t_blas = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     // ---- TLAS over meshes ----
     std::vector<Box> mesh_boxes(static_cast<size_t>(n_meshes));
     for (int m = 0; m < n_meshes; ++m) {
@@ -364,19 +630,25 @@ Scene* build_scene(int n_meshes, const double* const* coords, const double* cons
     sc->prim_mesh.resize(static_cast<size_t>(total_tris));
     sc->prim_elem.resize(static_cast<size_t>(total_tris));
 
-    std::vector<int32_t> slot_need(n_slots, 0);
-    for (int s = 0; s < n_slots; ++s) {
+    std::vector<int32_t> slot_need(n_slots, 0), slot_max_leaf(n_slots, 0);
+    std::vector<std::vector<int64_t>> big_leaves(n_slots);  // leaves that need a leaf_ext entry, in sweep order
+    Pool::get().parallel_for(n_slots, [&](int64_t s) {
         const HostBlas& b = sc->slots[s];
         const int64_t E = static_cast<int64_t>(b.sorted_to_elem.size());
         const double* ct = coords[b.mesh] + static_cast<int64_t>(timestep) * E * 9;
         const double* kt = colors[b.mesh] + static_cast<int64_t>(timestep) * E * 3;
         const int64_t tb = sc->slot_tri_base[s];
-        for (int64_t p = 0; p < E; ++p) {
-            const int64_t e = b.sorted_to_elem[p];
-            std::memcpy(&sc->tris[(tb + p) * 9], ct + e * 9, 9 * sizeof(double));
-            std::memcpy(&sc->colors[(tb + p) * 3], kt + e * 3, 3 * sizeof(double));
-            sc->prim_mesh[tb + p] = b.mesh;
-            sc->prim_elem[tb + p] = static_cast<int32_t>(e);
+        {
+            int64_t nc = 0;
+            for_chunks(0, E, nc, [&](int64_t, int64_t lo, int64_t hi) {
+                for (int64_t p = lo; p < hi; ++p) {
+                    const int64_t e = b.sorted_to_elem[p];
+                    std::memcpy(&sc->tris[(tb + p) * 9], ct + e * 9, 9 * sizeof(double));
+                    std::memcpy(&sc->colors[(tb + p) * 3], kt + e * 3, 3 * sizeof(double));
+                    sc->prim_mesh[tb + p] = b.mesh;
+                    sc->prim_elem[tb + p] = static_cast<int32_t>(e);
+                }
+            });
         }
         const int64_t nb = slot_node_base[s] + 1;
         sc->slot_root[s] = static_cast<int32_t>(nb);
@@ -392,8 +664,11 @@ Scene* build_scene(int n_meshes, const double* const* coords, const double* cons
                 d.left = -1;
                 d.count = static_cast<int32_t>(h.count);
                 d.first = static_cast<int32_t>(tb + h.first);
-                d.desc = leaf_desc(tb + h.first, h.count, sc->leaf_ext);
-                sc->max_leaf_tris = std::max<int32_t>(sc->max_leaf_tris, static_cast<int32_t>(h.count));
+                if (h.count >= 1 && h.count <= 7)
+                    d.desc = DESC_LEAF | (static_cast<uint32_t>(h.count - 1) << 28) | static_cast<uint32_t>(tb + h.first);
+                else
+                    big_leaves[s].push_back(i);  // leaf_ext slots are handed out below, in a fixed order
+                slot_max_leaf[s] = std::max<int32_t>(slot_max_leaf[s], static_cast<int32_t>(h.count));
                 need[i] = 0;
             } else {
                 d.left = static_cast<int32_t>(nb + h.left);
@@ -404,6 +679,14 @@ Scene* build_scene(int n_meshes, const double* const* coords, const double* cons
             }
         }
         slot_need[s] = need[0];
+    });
+    for (int s = 0; s < n_slots; ++s) {
+        sc->max_leaf_tris = std::max(sc->max_leaf_tris, slot_max_leaf[s]);
+        const int64_t nb = slot_node_base[s] + 1, tb = sc->slot_tri_base[s];
+        for (int64_t i : big_leaves[s]) {
+            const HostNode& h = sc->slots[s].nodes[i];
+            sc->dev_nodes[nb + i].desc = leaf_desc(tb + h.first, h.count, sc->leaf_ext);
+        }
     }
 
     // TLAS device nodes + stack need (entries above the base while a popped node is processed)
@@ -430,15 +713,28 @@ Scene* build_scene(int n_meshes, const double* const* coords, const double* cons
     }
     sc->stack_need = std::max(1, tneed[0]) + 1;
     {
+        const int64_t nv = static_cast<int64_t>(sc->tris.size());
+        const int64_t max_chunks = nv < kParMin ? 1 : (nv + kParChunk - 1) / kParChunk;
+        std::vector<double> part(static_cast<size_t>(max_chunks), 0.0);
+        int64_t nc = 0;
+        for_chunks(0, nv, nc, [&](int64_t c, int64_t lo, int64_t hi) {
+            double m = 0.0;
+            for (int64_t i = lo; i < hi; ++i) {
+                const double a = std::fabs(sc->tris[i]);
+                if (!(a <= m)) m = (a == a) ? a : kInf;  // NaN -> inf
+            }
+            part[c] = m;
+        });
         double m = 0.0;
-        for (double v : sc->tris) {
-            const double a = std::fabs(v);
-            if (!(a <= m)) m = (a == a) ? a : kInf;  // NaN -> inf
-        }
+        for (int64_t c = 0; c < nc; ++c)
+            if (!(part[c] <= m)) m = part[c];
         sc->max_abs_coord = m;
     }
 
     sc->build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+    if (std::getenv("RT_BUILD_TIMING"))
+        std::fprintf(stderr, "rt_scene_build: %lld triangles, BLAS builds %.1f ms, TLAS + flatten %.1f ms\n",
+                     (long long)total_tris, t_blas * 1e3, (sc->build_seconds - t_blas) * 1e3);
     return sc.release();
 }
 

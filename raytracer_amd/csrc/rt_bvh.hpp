@@ -5,6 +5,8 @@
 // triangle array in leaf order, one colour array, a slot table.  See DESIGN.md "Data layout".
 #pragma once
 #include <cstdint>
+#include <new>
+#include <utility>
 #include <vector>
 
 namespace rt {
@@ -53,19 +55,45 @@ constexpr uint32_t DESC_NONE = 0xFFFFFFFFu;  // never a real descriptor (< 2^28 
 constexpr int64_t MAX_DEV_NODES = (1ll << 29) - 2;
 constexpr int64_t MAX_TRIS = (1ll << 28) - 1;
 
+// std::vector allocator that default-initialises (leaves trivially constructible elements untouched)
+// on resize: the big flat arrays are written exactly once, by several threads, right after they are
+// sized; zero-filling them first would be a serial pass over a gigabyte.
+template <class T>
+struct NoInitAlloc {
+    using value_type = T;
+    NoInitAlloc() = default;
+    template <class U>
+    NoInitAlloc(const NoInitAlloc<U>&) {}
+    T* allocate(size_t n) { return static_cast<T*>(::operator new(n * sizeof(T))); }
+    void deallocate(T* p, size_t) { ::operator delete(p); }
+    template <class U, class... A>
+    void construct(U* p, A&&... a) {
+        if constexpr (sizeof...(A) == 0)
+            ::new (static_cast<void*>(p)) U;
+        else
+            ::new (static_cast<void*>(p)) U(std::forward<A>(a)...);
+    }
+    template <class U>
+    bool operator==(const NoInitAlloc<U>&) const { return true; }
+    template <class U>
+    bool operator!=(const NoInitAlloc<U>&) const { return false; }
+};
+template <class T>
+using FlatVec = std::vector<T, NoInitAlloc<T>>;
+
 struct Scene {
     // host tree
     std::vector<HostNode> tlas;       // reference numbering
     std::vector<HostBlas> slots;      // tlas.blases: *stored* order (rtbvh.cpp:544-561, quirk 1)
     std::vector<int64_t> slot_tri_base;
     // device arrays
-    std::vector<DevNode> dev_nodes;   // BLAS nodes of all slots; slot s root at slot_root[s]
+    FlatVec<DevNode> dev_nodes;       // BLAS nodes of all slots; slot s root at slot_root[s]
     std::vector<DevNode> dev_tlas;    // TLAS nodes (left = TLAS index, first = min_blas_idx)
     std::vector<int32_t> slot_root;   // device node index of each slot's root
     std::vector<uint32_t> leaf_ext;   // {first, count} pairs for leaves with > 7 triangles
-    std::vector<double> tris;         // n_tris * 9, leaf (sorted) order, slot after slot
-    std::vector<double> colors;       // n_tris * 3, same order
-    std::vector<int32_t> prim_mesh, prim_elem;  // prim id -> original ids
+    FlatVec<double> tris;             // n_tris * 9, leaf (sorted) order, slot after slot
+    FlatVec<double> colors;           // n_tris * 3, same order
+    FlatVec<int32_t> prim_mesh, prim_elem;      // prim id -> original ids
     int32_t stack_need = 1;
     double max_abs_coord = 0.0;  // max |vertex coordinate|; +inf if any coordinate is NaN/inf
     int32_t max_leaf_tris = 0;

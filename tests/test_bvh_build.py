@@ -148,3 +148,17 @@ def test_stack_need_covers_depth():
         depth[s["left"][i]] = depth[i] + 1
         depth[s["left"][i] + 1] = depth[i] + 1
     assert 2 <= p.info.stack_need <= depth.max() + 3
+
+
+def test_large_meshes_take_the_parallel_build_and_match_the_serial_oracle():
+    """>= 131072 triangles: the top of the tree is expanded with chunk-parallel scans and the subtrees are
+    built concurrently and spliced (rt_bvh.cpp build_tree); the result must still equal the oracle's
+    serial build node for node -- boxes bit for bit, permutation, numbering, fallback count."""
+    c, k = meshgen.plate(300)  # 180,000 triangles, regular grid (many equal centroid coordinates)
+    o, p = assert_same_tree([c], [k])
+    assert p.info.n_tris == 180000
+    # irregular soup with duplicates (ties in the partition, degenerate bins) next to a second big mesh
+    c2, k2 = meshgen.random_soup(150000, seed=9, extent=40.0, size=0.4)
+    c2[0, 1000:2000] = c2[0, :1000]
+    c3, k3 = meshgen.plate(260, x0=50.0, y0=-3.0)
+    assert_same_tree([c2, c3], [k2, k3])
