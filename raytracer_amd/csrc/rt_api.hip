@@ -95,6 +95,17 @@ struct rt_ctx {
     DevBuf<int32_t> slot_root;
     DevBuf<uint32_t> leaf_ext;
     DevBuf<double> tris, colors;
+    // Second set of scene buffers: rt_upload_scene fills it on copy_stream while kernels launched
+    // earlier still read the current set, then the two sets trade places.
+    struct BackScene {
+        DevBuf<rt::DevNode> nodes, tlas;
+        DevBuf<int32_t> slot_root;
+        DevBuf<uint32_t> leaf_ext;
+        DevBuf<double> tris, colors;
+    } back;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t front_last_use = nullptr, back_last_use = nullptr;  // last render launched on each set
+    bool front_used = false, back_used = false;
     // camera-relative copies for the packet kernel (rebuilt per render by the prep kernels)
     DevBuf<rt::DevNode> cam_nodes, cam_tlas;
     DevBuf<rtk::CamTri> cam_tris;
@@ -480,6 +491,12 @@ rt_ctx* rt_create(int device) {
     // must be dispatched between the workgroups of the long traversal kernel, not after it
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->front_last_use, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->back_last_use, hipEventDisableTiming) != hipSuccess) {
+        g_err = "rt_create: copy stream / events";
+        return nullptr;
+    }
     const char* pe = std::getenv("RT_RNG_PRIO");  // tuning knob: "lo" = same priority as the traversal stream
     const int prio_rng = (pe && pe[0] == 'l') ? prio_lo : prio_hi;
     if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_lo) != hipSuccess ||
@@ -560,6 +577,15 @@ void rt_destroy(rt_ctx* c) {
     c->tr_p.release();
     for (auto& ev : c->ev)
         if (ev) (void)hipEventDestroy(ev);
+    c->back.nodes.release();
+    c->back.tlas.release();
+    c->back.slot_root.release();
+    c->back.leaf_ext.release();
+    c->back.tris.release();
+    c->back.colors.release();
+    if (c->front_last_use) (void)hipEventDestroy(c->front_last_use);
+    if (c->back_last_use) (void)hipEventDestroy(c->back_last_use);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->rng_stream) (void)hipStreamDestroy(c->rng_stream);
     delete c;
@@ -577,35 +603,43 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* scene) {
     if (!c || !scene) return fail(RT_E_INVALID, "rt_upload_scene: null argument");
     const rt::Scene& s = *scene->s;
     HIP_TRY(hipSetDevice(c->device));
-    // the previous frame's kernels may still be reading the old tree
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    // The upload goes into the back set on its own stream, so a render launched before this call keeps
+    // running on the current set.  The back set was the current one two uploads ago: wait for the last
+    // render that used it.
+    if (c->back_used) HIP_TRY(hipEventSynchronize(c->back_last_use));
+    rt_ctx::BackScene& bk = c->back;
     int rc;
-    if ((rc = c->nodes.ensure(s.dev_nodes.size()))) return rc;
-    if ((rc = c->tlas.ensure(s.dev_tlas.size()))) return rc;
-    if ((rc = c->slot_root.ensure(s.slot_root.size()))) return rc;
-    if ((rc = c->leaf_ext.ensure(std::max<size_t>(s.leaf_ext.size(), 2)))) return rc;
-    if ((rc = c->tris.ensure(s.tris.size()))) return rc;
-    if ((rc = c->colors.ensure(s.colors.size()))) return rc;
-    if ((rc = c->cam_nodes.ensure(s.dev_nodes.size()))) return rc;
-    if ((rc = c->cam_tlas.ensure(s.dev_tlas.size()))) return rc;
-    if ((rc = c->cam_tris.ensure(s.prim_mesh.size()))) return rc;
+    if ((rc = bk.nodes.ensure(s.dev_nodes.size()))) return rc;
+    if ((rc = bk.tlas.ensure(s.dev_tlas.size()))) return rc;
+    if ((rc = bk.slot_root.ensure(s.slot_root.size()))) return rc;
+    if ((rc = bk.leaf_ext.ensure(std::max<size_t>(s.leaf_ext.size(), 2)))) return rc;
+    if ((rc = bk.tris.ensure(s.tris.size()))) return rc;
+    if ((rc = bk.colors.ensure(s.colors.size()))) return rc;
+    hipStream_t cs = c->copy_stream;
+    HIP_TRY(hipMemcpyAsync(bk.nodes.p, s.dev_nodes.data(), s.dev_nodes.size() * sizeof(rt::DevNode), hipMemcpyHostToDevice,
+                           cs));
+    HIP_TRY(hipMemcpyAsync(bk.tlas.p, s.dev_tlas.data(), s.dev_tlas.size() * sizeof(rt::DevNode), hipMemcpyHostToDevice, cs));
+    HIP_TRY(hipMemcpyAsync(bk.slot_root.p, s.slot_root.data(), s.slot_root.size() * sizeof(int32_t), hipMemcpyHostToDevice,
+                           cs));
+    if (!s.leaf_ext.empty())
+        HIP_TRY(hipMemcpyAsync(bk.leaf_ext.p, s.leaf_ext.data(), s.leaf_ext.size() * sizeof(uint32_t), hipMemcpyHostToDevice,
+                               cs));
+    HIP_TRY(hipMemcpyAsync(bk.tris.p, s.tris.data(), s.tris.size() * sizeof(double), hipMemcpyHostToDevice, cs));
+    HIP_TRY(hipMemcpyAsync(bk.colors.p, s.colors.data(), s.colors.size() * sizeof(double), hipMemcpyHostToDevice, cs));
+    // the host vectors are pageable and may be freed by the caller right away: wait for the copies
+    // (only for them -- the traversal stream is not touched)
+    HIP_TRY(hipStreamSynchronize(cs));
+    std::swap(c->nodes, bk.nodes);
+    std::swap(c->tlas, bk.tlas);
+    std::swap(c->slot_root, bk.slot_root);
+    std::swap(c->leaf_ext, bk.leaf_ext);
+    std::swap(c->tris, bk.tris);
+    std::swap(c->colors, bk.colors);
+    std::swap(c->front_last_use, c->back_last_use);
+    std::swap(c->front_used, c->back_used);
+    c->front_used = false;
     c->n_nodes = s.dev_nodes.size();
     c->n_tlas = s.dev_tlas.size();
-    HIP_TRY(hipMemcpyAsync(c->nodes.p, s.dev_nodes.data(), s.dev_nodes.size() * sizeof(rt::DevNode),
-                           hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->tlas.p, s.dev_tlas.data(), s.dev_tlas.size() * sizeof(rt::DevNode),
-                           hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->slot_root.p, s.slot_root.data(), s.slot_root.size() * sizeof(int32_t),
-                           hipMemcpyHostToDevice, c->stream));
-    if (!s.leaf_ext.empty())
-        HIP_TRY(hipMemcpyAsync(c->leaf_ext.p, s.leaf_ext.data(), s.leaf_ext.size() * sizeof(uint32_t),
-                               hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->tris.p, s.tris.data(), s.tris.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->colors.p, s.colors.data(), s.colors.size() * sizeof(double), hipMemcpyHostToDevice,
-                           c->stream));
-    // host vectors are pageable: the copies have been staged when the calls return, but the
-    // scene may be freed by the caller right away, so wait for them here.
-    HIP_TRY(hipStreamSynchronize(c->stream));
     c->stack_need = s.stack_need;
     c->max_abs_coord = s.max_abs_coord;
     c->n_tris = (int64_t)s.prim_mesh.size();
@@ -818,6 +852,9 @@ int rt_render(rt_ctx* c, const rt_render_params* p) {
         HIP_TRY(hipEventRecord(c->ev[1], c->stream));
     } else if (packet) {
         // Wave-packet traversal on camera-relative records (see rt_kernels.hip.hpp).
+        if ((rc = c->cam_nodes.ensure(c->n_nodes))) return rc;
+        if ((rc = c->cam_tlas.ensure(c->n_tlas))) return rc;
+        if ((rc = c->cam_tris.ensure((size_t)c->n_tris))) return rc;
         const double ox = p->camera_center[0], oy = p->camera_center[1], oz = p->camera_center[2];
         hipLaunchKernelGGL(rtk::prep_nodes_kernel, dim3((unsigned)((c->n_nodes + 255) / 256)), dim3(256), 0, c->stream,
                            c->nodes.p, c->cam_nodes.p, (long long)c->n_nodes, ox, oy, oz);
@@ -903,6 +940,8 @@ int rt_render(rt_ctx* c, const rt_render_params* p) {
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->ev[1], c->stream));
     }
+    HIP_TRY(hipEventRecord(c->front_last_use, c->stream));  // rt_upload_scene waits for it before reusing the set
+    c->front_used = true;
     c->timing_pending = true;
     c->out_rows = rows;
     c->out_w = W;
@@ -1140,7 +1179,9 @@ int rt_render_scene(int image_height, int image_width, int number_of_samples, co
             if (writer.valid()) writer.get();
             return code;
         };
-        if (t != built_t) {  // frames arrive timestep-major: one build per timestep this rank touches
+        // frames arrive timestep-major: one build + upload per timestep this rank touches.  Returns 0 or
+        // an error code (after cleaning up).
+        auto advance_scene = [&](int t_new) -> int {
             double t0 = now();
             Built b = pending.front().get();
             pending.pop_front();
@@ -1154,12 +1195,14 @@ int rt_render_scene(int image_height, int image_width, int number_of_samples, co
             for (int64_t k = 0; k < b.sc->s->midpoint_fallbacks; ++k)
                 std::printf("SAH splitting failed. Trying midpoint instead.\n");  // cpp/rtbvh.cpp:128
             t0 = now();
-            rc = rt_upload_scene(c, b.sc);
+            const int urc = rt_upload_scene(c, b.sc);
             t_upload += now() - t0;
             rt_scene_free(b.sc);
-            if (rc) return bail(rc);
-            built_t = t;
-        }
+            if (urc) return bail(urc);
+            built_t = t_new;
+            return RT_OK;
+        };
+        if (t != built_t && (rc = advance_scene(t))) return rc;
         if ((rc = rt_rng_seek(c, my_pos[q]))) return bail(rc);
         std::printf("Rendering frame %d/%d\n", t + 1, timestep_count);  // cpp/rtmain.cpp:61
         std::fflush(stdout);
@@ -1177,6 +1220,12 @@ int rt_render_scene(int image_height, int image_width, int number_of_samples, co
         double t1 = now();
         if ((rc = rt_render(c, &p))) return bail(rc);
         t_render += now() - t1;
+        // the tree of the next timestep goes to the GPU (second buffer set, copy stream) while this
+        // timestep's last frame is still rendering
+        if (q + 1 < n_mine) {
+            const int t_next = (int)(my_frames[q + 1] / n_cameras);
+            if (t_next != built_t && (rc = advance_scene(t_next))) return rc;
+        }
         t1 = now();
         if (writer.valid()) writer.get();  // previous file done (it was being written while this frame rendered)
         uint8_t* dst = rgb2[wbuf].data();
