@@ -138,6 +138,10 @@ struct rt_ctx {
         int rows = 0, W = 0, spp = 0;
         hipEvent_t done = nullptr, t0 = nullptr, t1 = nullptr;
         double host_ms = 0.0;
+        // what d_states holds (survives `valid = false`): n states, `stride` words apart, from states_pos
+        bool states_ok = false;
+        uint64_t states_pos = 0, states_stride = 0;
+        int states_n = 0;
     } slot[2];
     int last_slot = 0;
     bool have_last_start = false;
@@ -217,14 +221,18 @@ struct StreamPlan {
 
 StreamPlan plan_streams(int rows, int W, int spp) {
     StreamPlan p;
-    // one wave per stream; jumps run on the GPU (~0.1 ms each, a level in parallel), so streams are
-    // cheap: up to 2048, none shorter than 2^16 words
+    // One wave per stream.  Measured: a stream regenerates 624 words in ~2 us (LDS-latency bound), i.e.
+    // 3.2 ns/word, and one jump costs ~1.2 us of the whole GPU.  The traversal kernel needs ~0.015 ns per
+    // word, so ~450 streams already keep the jitter kernel shorter than half the traversal it hides
+    // behind, whatever the frame size; more streams only add jump work.  Up to 512 streams, none shorter
+    // than 2^16 words; strides are whole regenerations, not whole rows.
     const uint64_t words = uint64_t(rows) * uint64_t(W) * uint64_t(spp) * 4u;
-    int target = (int)std::min<uint64_t>(2048, std::max<uint64_t>(1, words >> 16));
-    if (const char* e = std::getenv("RT_JITTER_STREAMS")) target = std::max(1, std::atoi(e));
-    const int R = std::max(1, (rows + target - 1) / target);
-    p.n = (rows + R - 1) / R;
-    p.stride = uint64_t(R) * uint64_t(W) * uint64_t(spp) * 4u;
+    uint64_t target = std::min<uint64_t>(512, std::max<uint64_t>(1, words >> 16));
+    if (const char* e = std::getenv("RT_JITTER_STREAMS")) target = (uint64_t)std::max(1, std::atoi(e));
+    uint64_t stride = (words + target - 1) / target;
+    stride = (stride + 623) / 624 * 624;
+    p.n = (int)((words + stride - 1) / stride);
+    p.stride = stride;
     p.total_words = words;
     return p;
 }
@@ -314,9 +322,33 @@ int fill_slot(rt_ctx* c, int k, uint64_t ahead, int rows, int W, int spp) {
     if ((rc = sl.d_end.ensure(rt::MT_N))) return rc;
     const double t0 = now_ms();
     HIP_TRY(hipEventRecord(sl.t0, c->rng_stream));
-    if ((rc = dev_jump(c, c->d_state.p, sl.d_states.p, ahead))) return rc;
-    if ((rc = dev_jump(c, sl.d_states.p, sl.d_end.p, pl.total_words))) return rc;
-    if ((rc = launch_jitter(c, sl.d_states.p, pl, sl.buf.p))) return rc;
+    // Steady state of a frame loop: the other slot holds the stream states of a launch of the same
+    // shape D words earlier -> every state advances by D in ONE launch (instead of one jump to the
+    // start plus a doubling tree of log2(n) dependent launches).
+    const rt_ctx::JitterSlot& ot = c->slot[1 - k];
+    const uint64_t new_pos = c->pos + ahead;
+    sl.states_ok = false;
+    if (ot.states_ok && ot.states_n == pl.n && ot.states_stride == pl.stride && new_pos > ot.states_pos &&
+        !std::getenv("RT_NO_STATE_REUSE")) {  // (tuning knob)
+        const unsigned long long* poly = nullptr;
+        if ((rc = dev_poly(c, new_pos - ot.states_pos, &poly))) return rc;
+        HIP_TRY(hipMemsetAsync(sl.d_states.p, 0, size_t(pl.n) * sizeof(rt::MtState), c->rng_stream));
+        hipLaunchKernelGGL(rtk::mt_jump_all_kernel, dim3(pl.n, rtk::JUMP_PARTS), dim3(rtk::JUMP_THREADS), kJumpLds,
+                           c->rng_stream, ot.d_states.p, sl.d_states.p, poly);
+        HIP_TRY(hipGetLastError());
+        if ((rc = dev_jump(c, sl.d_states.p, sl.d_end.p, pl.total_words))) return rc;
+        hipLaunchKernelGGL(rtk::mt_jitter_kernel, dim3(pl.n), dim3(64), 0, c->rng_stream, sl.d_states.p, sl.buf.p,
+                           (unsigned long long)(pl.stride / 2), (unsigned long long)(pl.total_words / 2));
+        HIP_TRY(hipGetLastError());
+    } else {
+        if ((rc = dev_jump(c, c->d_state.p, sl.d_states.p, ahead))) return rc;
+        if ((rc = dev_jump(c, sl.d_states.p, sl.d_end.p, pl.total_words))) return rc;
+        if ((rc = launch_jitter(c, sl.d_states.p, pl, sl.buf.p))) return rc;
+    }
+    sl.states_ok = true;
+    sl.states_pos = new_pos;
+    sl.states_stride = pl.stride;
+    sl.states_n = pl.n;
     HIP_TRY(hipEventRecord(sl.t1, c->rng_stream));
     HIP_TRY(hipEventRecord(sl.done, c->rng_stream));
     sl.host_ms = now_ms() - t0;
@@ -657,7 +689,7 @@ int rt_rng_seed(rt_ctx* c, uint32_t seed) {
     rt::mt_seed(c->h_seed_state, seed);
     HIP_TRY(hipMemcpyAsync(c->d_state.p, c->h_seed_state.w, sizeof(rt::MtState), hipMemcpyHostToDevice, c->rng_stream));
     c->pos = 0;
-    for (auto& sl : c->slot) sl.valid = false;  // slots belong to the old seed's stream
+    for (auto& sl : c->slot) sl.valid = sl.states_ok = false;  // slots belong to the old seed's stream
     c->have_last_start = false;
     return RT_OK;
 }

@@ -1163,4 +1163,14 @@ __global__ __launch_bounds__(JUMP_THREADS) void mt_jump_tree_kernel(uint32_t* st
     mt_jump_block(states + srci * 624, states + dsti * 624, poly, blockIdx.y, jump_x);
 }
 
+// every stream state advanced by the same distance: dst[i] = g(A) src[i], grid (n, JUMP_PARTS); dst zeroed
+// beforehand.  A frame loop with a constant distance between frames needs only this one launch per frame
+// instead of the doubling tree.
+__global__ __launch_bounds__(JUMP_THREADS) void mt_jump_all_kernel(const uint32_t* src, uint32_t* dst,
+                                                                   const unsigned long long* poly) {
+    extern __shared__ uint32_t jump_x[];
+    const long long i = blockIdx.x;
+    mt_jump_block(src + i * 624, dst + i * 624, poly, blockIdx.y, jump_x);
+}
+
 }  // namespace rtk
