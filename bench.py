@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+TDEV = "cuda"  # device of the tensors handed to torch.distributed (see RT_BENCH_BACKEND)
 
 
 def workload(name):
@@ -182,7 +183,7 @@ def bench_multiframe(ra, rank, world, local_rank, dist, steps_per_rank=16):
     elapsed = time.perf_counter() - t0
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=TDEV)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     n_files = len([f for f in os.listdir(out_dir) if f.endswith(".ppm")])
@@ -216,8 +217,17 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # RT_BENCH_BACKEND=gloo: rehearsal of the N > 1 logic on a box with fewer GPUs than ranks (ranks share
+        # GPUs, collectives on the host); the driver's runs use the default, RCCL
+        global TDEV
+        if os.environ.get("RT_BENCH_BACKEND", "nccl") == "gloo":
+            local_rank = local_rank % max(1, torch.cuda.device_count())
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("gloo")
+            TDEV = "cpu"
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import raytracer_amd as ra
 
@@ -267,7 +277,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=TDEV)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -275,6 +285,45 @@ def main():
     # rt_render_scene -- per-timestep host BVH rebuild (TLAS + 8 BLAS), upload, 2 cameras x 50 spp,
     # read-back, P6 files -- frames sharded over ranks, no collective.  configs[4]-shaped, weak scaling.
     multiframe = None if args.no_multiframe else bench_multiframe(ra, rank, world, local_rank, dist)
+
+    # N > 1 only: ONE frame of the same workload split into row bands over the ranks (SURVEY 8(e), strong
+    # scaling): every rank renders its band at its own stream position, then the bands are gathered on rank 0
+    # (RCCL gather of the f64 intensity bands).  Reported in aux, never part of `value`.
+    banded = None
+    if world > 1:
+        try:
+            import torch
+            r0, r1, pos = ra.shard_rows(H, W, spp, rank, world, 0)
+
+            def band_step():
+                if r1 > r0:
+                    ctx.rng_seek(pos)
+                    ctx.render(*cam, H, W, spp, rows=(r0, r1), hit_ids=want_ids)
+
+            band_step()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                band_step()
+            barrier()
+            t_render = (time.perf_counter() - t0) / args.steps
+            t0 = time.perf_counter()
+            band = ctx.download(rgb=False, hit_ids=False)["intensity"] if r1 > r0 else np.empty((0, W))
+            sizes = [ra.shard_rows(H, W, spp, r, world, 0) for r in range(world)]
+            pad = max(b - a for a, b, _ in sizes)
+            mine = torch.zeros(pad, W, dtype=torch.float64, device=TDEV)
+            mine[: r1 - r0] = torch.from_numpy(band).to(TDEV)
+            parts = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
+            dist.gather(mine, parts, dst=0)
+            torch.cuda.synchronize()
+            t_gather = time.perf_counter() - t0
+            tt = torch.tensor([t_render, t_gather], dtype=torch.float64, device=TDEV)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            banded = {"ms_per_frame_render": float(tt[0]) * 1e3, "mrays_per_s": rays_per_frame / float(tt[0]) / 1e6,
+                      "download_plus_gather_ms": float(tt[1]) * 1e3, "bands": [[a, b] for a, b, _ in sizes],
+                      "scaling": "strong"}
+        except Exception as e:
+            banded = {"error": str(e)}
 
     # untimed extras on rank 0: per-launch kernel time over several launches, visit counters, CPU baseline
     out = None
@@ -381,7 +430,7 @@ def main():
                     "upload_s": upload_s, "stack_need": int(host.info.stack_need),
                     "download_frame_ms": dl_frame_ms, "download_hit_ids_ms": dl_ids_ms,
                     "kernel_ms_timed_step": kernel_ms[-1] if kernel_ms else None,
-                    "multiframe": multiframe, "fp32_fast_path": fp32},
+                    "multiframe": multiframe, "fp32_fast_path": fp32, "single_frame_banded": banded},
         }
     if dist is not None:
         dist.barrier()

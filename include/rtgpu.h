@@ -205,6 +205,16 @@ int rt_render_scene(int image_height, int image_width, int number_of_samples, co
 int64_t rt_shard_frames(int timestep_count, int n_cameras, int rank, int world, uint64_t stream_base,
                         uint64_t frame_words, int64_t capacity, int64_t *frames, uint64_t *positions);
 
+/* Host-only: the row-band schedule for ONE big frame rendered by several GPUs (the tree is
+ * replicated, the image split into contiguous row bands, no collective but the gather of the bands).
+ * Rank `rank` of `world` renders rows [*row_begin, *row_end) -- possibly empty -- with rt_render's
+ * row_begin/row_end after rt_rng_seek(*stream_position): the band starts at
+ * frame_base + row_begin*W*spp*4 of the reference's stream (cpp/rtrender.cpp:47-60 draws row-major),
+ * so the assembled image is the one a single rank renders.  Band boundaries fall on multiples of 8 rows
+ * when image_height >= 8*world.  No counterpart in the reference (it has one thread and one frame loop). */
+int rt_shard_rows(int image_height, int image_width, int number_of_samples, int rank, int world, uint64_t frame_base,
+                  int *row_begin, int *row_end, uint64_t *stream_position);
+
 /* P6 writer: "P6\nW H\n255\n" + payload (rtrender.cpp:69-81). Prints the
  * reference's messages ("Failed to open the output file." / " Done."). */
 int rt_write_ppm(const char *path, int width, int height, const uint8_t *rgb);

@@ -225,6 +225,31 @@ def shard_frames(timestep_count, n_cameras, rank, world, stream_base=0, frame_wo
     return frames[:n], pos[:n]
 
 
+def shard_rows(H, W, spp, rank, world, frame_base=0):
+    """(row_begin, row_end, stream_position) of rank `rank`'s band of ONE frame split over `world` GPUs."""
+    r0, r1, pos = C.c_int(), C.c_int(), C.c_uint64()
+    L.check(lib.rt_shard_rows(int(H), int(W), int(spp), int(rank), int(world), int(frame_base), C.byref(r0), C.byref(r1),
+                              C.byref(pos)), "rt_shard_rows")
+    return r0.value, r1.value, pos.value
+
+
+def render_frame_banded(ctx, cam, p00, spacing, H, W, spp, rank, world, frame_base=0, gather=None, **render_kw):
+    """One frame over `world` GPUs: this rank renders its row band (tree replicated, no data-path
+    collective) and `gather(band_intensity, band_rgb, row_begin, row_end)` -- e.g. a torch.distributed
+    gather to rank 0 -- assembles the framebuffer.  Leaves the context's stream position at the END of
+    the frame on every rank, like an unsharded render.  Returns whatever `gather` returns (or the band)."""
+    r0, r1, pos = shard_rows(H, W, spp, rank, world, frame_base)
+    band = {"intensity": np.empty((0, W)), "rgb": np.empty((0, W, 3), np.uint8)}
+    if r1 > r0:
+        ctx.rng_seek(pos)
+        ctx.render(cam, p00, spacing, H, W, spp, rows=(r0, r1), **render_kw)
+        band = ctx.download(hit_ids=False, hit_t=False)
+    ctx.rng_seek(int(frame_base) + H * W * spp * 4)
+    if gather is None:
+        return band, (r0, r1)
+    return gather(band["intensity"], band["rgb"], r0, r1)
+
+
 def write_ppm(path, rgb):
     rgb = np.ascontiguousarray(rgb, np.uint8)
     h, w = rgb.shape[:2]

@@ -1134,6 +1134,26 @@ int64_t rt_shard_frames(int timestep_count, int n_cameras, int rank, int world, 
     return n;
 }
 
+int rt_shard_rows(int image_height, int image_width, int number_of_samples, int rank, int world, uint64_t frame_base,
+                  int* row_begin, int* row_end, uint64_t* stream_position) {
+    if (image_height < 1 || image_width < 1 || number_of_samples < 1 || world < 1 || rank < 0 || rank >= world ||
+        !row_begin || !row_end)
+        return fail(RT_E_INVALID, "rt_shard_rows: bad arguments");
+    // contiguous bands, boundaries on multiples of 8 rows (the traversal kernel's tile height) when the
+    // image is tall enough to give every rank a tile row; the last band takes the remainder
+    auto cut = [&](int r) -> int {
+        if (r >= world) return image_height;
+        const int64_t exact = int64_t(image_height) * r / world;
+        if (image_height < 8 * world) return (int)exact;
+        return (int)std::min<int64_t>(image_height, (exact + 4) / 8 * 8);
+    };
+    *row_begin = cut(rank);
+    *row_end = cut(rank + 1);
+    if (stream_position)
+        *stream_position = frame_base + uint64_t(*row_begin) * uint64_t(image_width) * uint64_t(number_of_samples) * 4u;
+    return RT_OK;
+}
+
 int rt_render_scene(int image_height, int image_width, int number_of_samples, const char* output_directory,
                     int timestep_count, int n_meshes, const double* const* coords, const double* const* colors,
                     const int64_t* elem_counts, int n_cameras, const double* camera_centers,

@@ -402,3 +402,27 @@ def test_device_jump_matches_host_jump_and_sequential(ctx):
     got = ctx.rng_jitter(1000, 3)
     assert np.array_equal(bits(got), bits(orc.Rng(42).doubles(1000) - 0.5))
     ctx.rng_seed(5489)
+
+
+def test_one_frame_in_row_bands_over_three_ranks_equals_the_full_frame(ctx):
+    """SURVEY 8(e), single big frame: every rank renders its band from rt_shard_rows at its own stream
+    position; the assembled frame is the single-GPU frame bit for bit (ranks simulated one after another
+    on this GPU) and every rank leaves the stream at the end of the frame."""
+    c, k = meshgen.plate(64)
+    H, W, spp, base = 70, 52, 5, 4 * 4321
+    cam = meshgen.camera_arrays(W, H)
+    ctx.upload(ra.HostScene([c], [k], 0))
+    ctx.rng_seed(5489)
+    ctx.rng_seek(base)
+    ctx.render(*cam, H, W, spp)
+    full = ctx.download()
+    inten = np.full((H, W), np.nan)
+    rgb = np.zeros((H, W, 3), np.uint8)
+    for rank in (2, 0, 1):
+        ctx.rng_seed(5489)
+        band, (r0, r1) = ra.render_frame_banded(ctx, *cam, H, W, spp, rank, 3, frame_base=base)
+        assert ctx.rng_tell() == base + H * W * spp * 4
+        inten[r0:r1] = band["intensity"]
+        rgb[r0:r1] = band["rgb"]
+    assert np.array_equal(bits(inten), bits(full["intensity"]))
+    assert np.array_equal(rgb, full["rgb"])
