@@ -106,6 +106,21 @@ struct rt_ctx {
     hipStream_t copy_stream = nullptr;
     hipEvent_t front_last_use = nullptr, back_last_use = nullptr;  // last render launched on each set
     bool front_used = false, back_used = false;
+    // rt_render_scene's helper threads stage the tree they just built into one of these sets themselves
+    // (own stream, off the calling thread); the calling thread then only swaps pointers (activate_staged).
+    struct StagedSet {
+        BackScene b;
+        hipStream_t stream = nullptr;
+        hipEvent_t last_use = nullptr;  // after a swap: last render on the buffers this set now holds
+        bool used = false;
+        int state = 0;  // 0 free, 1 being filled, 2 staged
+        size_t n_nodes = 0, n_tlas = 0;
+        int64_t n_tris = 0;
+        int32_t stack_need = 1;
+        double max_abs_coord = 0.0;
+    };
+    std::vector<std::unique_ptr<StagedSet>> staged;
+    std::mutex staged_mu;
     // camera-relative copies for the packet kernel (rebuilt per render by the prep kernels)
     DevBuf<rt::DevNode> cam_nodes, cam_tlas;
     DevBuf<rtk::CamTri> cam_tris;
@@ -211,12 +226,11 @@ void launch_trace(int stack, dim3 grid, hipStream_t st, const rtk::TraceArgs& a)
     }
 }
 
-// Streams of one jitter launch: rows are split into n groups of R rows; stream g covers rows
-// [g*R, (g+1)*R) and starts `stride` = R*W*spp*4 words after stream g-1.
+// Streams of one jitter launch: stream g produces the words [g*stride, (g+1)*stride) of the launch.
 struct StreamPlan {
     int n = 1;
     uint64_t stride = 0;       // words
-    uint64_t total_words = 0;  // rows*W*spp*4
+    uint64_t total_words = 0;  // rows*W*spp*4 (the last stream stops there)
 };
 
 StreamPlan plan_streams(int rows, int W, int spp) {
@@ -243,6 +257,11 @@ constexpr size_t kJumpLds = size_t(rtk::JUMP_LDS_WORDS) * sizeof(uint32_t);
 int dev_poly(rt_ctx* c, uint64_t stride, const unsigned long long** out) {
     auto it = c->d_polys.find(stride);
     if (it == c->d_polys.end()) {
+        if (c->d_polys.size() >= 1024) {  // bound the device-side cache: drop it once nothing uses it any more
+            HIP_TRY(hipStreamSynchronize(c->rng_stream));
+            for (auto& kv : c->d_polys) (void)hipFree(kv.second);
+            c->d_polys.clear();
+        }
         const rt::MtPoly& g = rt::mt_jump_poly(stride);  // may throw
         unsigned long long* d = nullptr;
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d), sizeof(g.b)));
@@ -357,6 +376,104 @@ int fill_slot(rt_ctx* c, int k, uint64_t ahead, int rows, int W, int spp) {
     sl.W = W;
     sl.spp = spp;
     sl.valid = true;
+    return RT_OK;
+}
+
+// host arrays of a built scene -> one set of device buffers, on `st`; waits for the copies (the host
+// vectors are pageable and their owner may free them right away)
+int copy_scene_to(rt_ctx::BackScene& bk, const rt::Scene& s, hipStream_t st) {
+    int rc;
+    if ((rc = bk.nodes.ensure(s.dev_nodes.size()))) return rc;
+    if ((rc = bk.tlas.ensure(s.dev_tlas.size()))) return rc;
+    if ((rc = bk.slot_root.ensure(s.slot_root.size()))) return rc;
+    if ((rc = bk.leaf_ext.ensure(std::max<size_t>(s.leaf_ext.size(), 2)))) return rc;
+    if ((rc = bk.tris.ensure(s.tris.size()))) return rc;
+    if ((rc = bk.colors.ensure(s.colors.size()))) return rc;
+    HIP_TRY(hipMemcpyAsync(bk.nodes.p, s.dev_nodes.data(), s.dev_nodes.size() * sizeof(rt::DevNode), hipMemcpyHostToDevice,
+                           st));
+    HIP_TRY(hipMemcpyAsync(bk.tlas.p, s.dev_tlas.data(), s.dev_tlas.size() * sizeof(rt::DevNode), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(bk.slot_root.p, s.slot_root.data(), s.slot_root.size() * sizeof(int32_t), hipMemcpyHostToDevice,
+                           st));
+    if (!s.leaf_ext.empty())
+        HIP_TRY(hipMemcpyAsync(bk.leaf_ext.p, s.leaf_ext.data(), s.leaf_ext.size() * sizeof(uint32_t), hipMemcpyHostToDevice,
+                               st));
+    HIP_TRY(hipMemcpyAsync(bk.tris.p, s.tris.data(), s.tris.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(bk.colors.p, s.colors.data(), s.colors.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return RT_OK;
+}
+
+void swap_sets(rt_ctx* c, rt_ctx::BackScene& bk) {
+    std::swap(c->nodes, bk.nodes);
+    std::swap(c->tlas, bk.tlas);
+    std::swap(c->slot_root, bk.slot_root);
+    std::swap(c->leaf_ext, bk.leaf_ext);
+    std::swap(c->tris, bk.tris);
+    std::swap(c->colors, bk.colors);
+}
+
+// Called on a helper thread: copy `s` into a free staged set.  Returns the set's index, or -1 when no
+// set is free or a HIP call failed (the caller then falls back to rt_upload_scene on its own thread).
+int stage_scene(rt_ctx* c, const rt::Scene& s) {
+    rt_ctx::StagedSet* st = nullptr;
+    int idx = -1;
+    {
+        std::lock_guard<std::mutex> lk(c->staged_mu);
+        for (size_t i = 0; i < c->staged.size(); ++i)
+            if (c->staged[i]->state == 0) {
+                st = c->staged[i].get();
+                st->state = 1;
+                idx = (int)i;
+                break;
+            }
+    }
+    if (!st) return -1;
+    auto give_up = [&]() {
+        std::lock_guard<std::mutex> lk(c->staged_mu);
+        st->state = 0;
+        return -1;
+    };
+    if (hipSetDevice(c->device) != hipSuccess) return give_up();
+    // these buffers may have been the current set until recently: wait for the last render that read them
+    if (st->used && hipEventSynchronize(st->last_use) != hipSuccess) return give_up();
+    st->used = false;
+    if (copy_scene_to(st->b, s, st->stream) != RT_OK) return give_up();
+    st->n_nodes = s.dev_nodes.size();
+    st->n_tlas = s.dev_tlas.size();
+    st->n_tris = (int64_t)s.prim_mesh.size();
+    st->stack_need = s.stack_need;
+    st->max_abs_coord = s.max_abs_coord;
+    std::lock_guard<std::mutex> lk(c->staged_mu);
+    st->state = 2;
+    return idx;
+}
+
+// Calling thread: make staged set `idx` the current scene (pointer swaps only); the set keeps the
+// previous scene's buffers, guarded by the event of the last render that used them.
+void activate_staged(rt_ctx* c, int idx) {
+    rt_ctx::StagedSet* st = c->staged[(size_t)idx].get();
+    swap_sets(c, st->b);
+    std::swap(c->front_last_use, st->last_use);
+    std::swap(c->front_used, st->used);
+    c->front_used = false;
+    c->n_nodes = st->n_nodes;
+    c->n_tlas = st->n_tlas;
+    c->n_tris = st->n_tris;
+    c->stack_need = st->stack_need;
+    c->max_abs_coord = st->max_abs_coord;
+    c->have_scene = true;
+    std::lock_guard<std::mutex> lk(c->staged_mu);
+    st->state = 0;
+}
+
+int ensure_staged_pool(rt_ctx* c, size_t n) {
+    std::lock_guard<std::mutex> lk(c->staged_mu);
+    while (c->staged.size() < n) {
+        std::unique_ptr<rt_ctx::StagedSet> st(new rt_ctx::StagedSet());
+        HIP_TRY(hipStreamCreateWithFlags(&st->stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&st->last_use, hipEventDisableTiming));
+        c->staged.push_back(std::move(st));
+    }
     return RT_OK;
 }
 
@@ -609,6 +726,17 @@ void rt_destroy(rt_ctx* c) {
     c->tr_p.release();
     for (auto& ev : c->ev)
         if (ev) (void)hipEventDestroy(ev);
+    for (auto& st : c->staged) {
+        st->b.nodes.release();
+        st->b.tlas.release();
+        st->b.slot_root.release();
+        st->b.leaf_ext.release();
+        st->b.tris.release();
+        st->b.colors.release();
+        if (st->last_use) (void)hipEventDestroy(st->last_use);
+        if (st->stream) (void)hipStreamDestroy(st->stream);
+    }
+    c->staged.clear();
     c->back.nodes.release();
     c->back.tlas.release();
     c->back.slot_root.release();
@@ -639,34 +767,9 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* scene) {
     // running on the current set.  The back set was the current one two uploads ago: wait for the last
     // render that used it.
     if (c->back_used) HIP_TRY(hipEventSynchronize(c->back_last_use));
-    rt_ctx::BackScene& bk = c->back;
     int rc;
-    if ((rc = bk.nodes.ensure(s.dev_nodes.size()))) return rc;
-    if ((rc = bk.tlas.ensure(s.dev_tlas.size()))) return rc;
-    if ((rc = bk.slot_root.ensure(s.slot_root.size()))) return rc;
-    if ((rc = bk.leaf_ext.ensure(std::max<size_t>(s.leaf_ext.size(), 2)))) return rc;
-    if ((rc = bk.tris.ensure(s.tris.size()))) return rc;
-    if ((rc = bk.colors.ensure(s.colors.size()))) return rc;
-    hipStream_t cs = c->copy_stream;
-    HIP_TRY(hipMemcpyAsync(bk.nodes.p, s.dev_nodes.data(), s.dev_nodes.size() * sizeof(rt::DevNode), hipMemcpyHostToDevice,
-                           cs));
-    HIP_TRY(hipMemcpyAsync(bk.tlas.p, s.dev_tlas.data(), s.dev_tlas.size() * sizeof(rt::DevNode), hipMemcpyHostToDevice, cs));
-    HIP_TRY(hipMemcpyAsync(bk.slot_root.p, s.slot_root.data(), s.slot_root.size() * sizeof(int32_t), hipMemcpyHostToDevice,
-                           cs));
-    if (!s.leaf_ext.empty())
-        HIP_TRY(hipMemcpyAsync(bk.leaf_ext.p, s.leaf_ext.data(), s.leaf_ext.size() * sizeof(uint32_t), hipMemcpyHostToDevice,
-                               cs));
-    HIP_TRY(hipMemcpyAsync(bk.tris.p, s.tris.data(), s.tris.size() * sizeof(double), hipMemcpyHostToDevice, cs));
-    HIP_TRY(hipMemcpyAsync(bk.colors.p, s.colors.data(), s.colors.size() * sizeof(double), hipMemcpyHostToDevice, cs));
-    // the host vectors are pageable and may be freed by the caller right away: wait for the copies
-    // (only for them -- the traversal stream is not touched)
-    HIP_TRY(hipStreamSynchronize(cs));
-    std::swap(c->nodes, bk.nodes);
-    std::swap(c->tlas, bk.tlas);
-    std::swap(c->slot_root, bk.slot_root);
-    std::swap(c->leaf_ext, bk.leaf_ext);
-    std::swap(c->tris, bk.tris);
-    std::swap(c->colors, bk.colors);
+    if ((rc = copy_scene_to(c->back, s, c->copy_stream))) return rc;  // waits for the copies only
+    swap_sets(c, c->back);
     std::swap(c->front_last_use, c->back_last_use);
     std::swap(c->front_used, c->back_used);
     c->front_used = false;
@@ -1189,13 +1292,17 @@ int rt_render_scene(int image_height, int image_width, int number_of_samples, co
     }
     struct Built {
         rt_scene* sc = nullptr;
+        int staged = -1;  // index of the device buffer set the helper thread filled, or -1
         std::string err;
     };
     auto build_async = [&](int t) {
         return std::async(std::launch::async, [=]() {
             Built b;
             b.sc = rt_scene_build(n_meshes, coords, colors, elem_counts, t, 0);
-            if (!b.sc) b.err = rt_last_error();  // thread-local message of the helper thread
+            if (!b.sc)
+                b.err = rt_last_error();  // thread-local message of the helper thread
+            else
+                b.staged = stage_scene(c, *b.sc->s);
             return b;
         });
     };
@@ -1215,9 +1322,17 @@ int rt_render_scene(int image_height, int image_width, int number_of_samples, co
         while (pending.size() < depth && next_step < my_steps.size()) pending.push_back(build_async(my_steps[next_step++]));
     };
     auto drain = [&]() {
-        for (auto& f : pending) rt_scene_free(f.get().sc);
+        for (auto& f : pending) {
+            Built b = f.get();
+            if (b.staged >= 0) {
+                std::lock_guard<std::mutex> lk(c->staged_mu);
+                c->staged[(size_t)b.staged]->state = 0;
+            }
+            rt_scene_free(b.sc);
+        }
         pending.clear();
     };
+    if ((rc = ensure_staged_pool(c, depth + 2))) return rc;
     // P6 files are written by a helper thread while the next frame renders (two host frame buffers)
     std::vector<uint8_t> rgb2[2] = {std::vector<uint8_t>(rgb_bytes), std::vector<uint8_t>(rgb_bytes)};
     std::future<void> writer;
@@ -1247,7 +1362,11 @@ int rt_render_scene(int image_height, int image_width, int number_of_samples, co
             for (int64_t k = 0; k < b.sc->s->midpoint_fallbacks; ++k)
                 std::printf("SAH splitting failed. Trying midpoint instead.\n");  // cpp/rtbvh.cpp:128
             t0 = now();
-            const int urc = rt_upload_scene(c, b.sc);
+            int urc = RT_OK;
+            if (b.staged >= 0)
+                activate_staged(c, b.staged);
+            else
+                urc = rt_upload_scene(c, b.sc);
             t_upload += now() - t0;
             rt_scene_free(b.sc);
             if (urc) return bail(urc);

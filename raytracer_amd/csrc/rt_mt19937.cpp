@@ -160,6 +160,8 @@ void mt_next_block(MtState& s) {
     w[MT_N - 1] = twist(w[MT_N - 1], w[0], w[396]);
 }
 
+constexpr size_t kMaxCachedPolys = 4096;  // 10 MB
+
 const MtPoly& mt_jump_poly(uint64_t stride) {
     {
         std::lock_guard<std::mutex> lk(g_cache_mu);
@@ -190,6 +192,13 @@ const MtPoly& mt_jump_poly(uint64_t stride) {
         }
     }
     std::lock_guard<std::mutex> lk(g_cache_mu);
+    // references into the map are handed out, so entries are never evicted: past the bound the result is
+    // returned through a per-thread slot instead (valid until this thread's next call), 2.5 KB per entry
+    if (g_cache.size() >= kMaxCachedPolys) {
+        thread_local MtPoly overflow;
+        overflow = r;
+        return overflow;
+    }
     return g_cache.emplace(stride, r).first->second;
 }
 
