@@ -426,3 +426,57 @@ def test_one_frame_in_row_bands_over_three_ranks_equals_the_full_frame(ctx):
         rgb[r0:r1] = band["rgb"]
     assert np.array_equal(bits(inten), bits(full["intensity"]))
     assert np.array_equal(rgb, full["rgb"])
+
+
+# ----------------------------------------------------------------------------------------------
+# The HIP path against the committed golden vectors themselves (tests/golden/eigen_probe.npz: values
+# produced by the reference's own rtmathutils.h and vendored Eigen, see oracle/make_golden.py).
+# ----------------------------------------------------------------------------------------------
+def test_gpu_jitter_equals_the_references_random_double_golden(ctx, golden_dir):
+    gold = np.load(os.path.join(golden_dir, "eigen_probe.npz"))
+    want = gold["rng_doubles"] - 0.5  # cpp/rtrender.cpp:53: random_double() - 0.5
+    ctx.rng_seed(5489)
+    got = ctx.rng_jitter(want.size, 3)
+    assert np.array_equal(bits(got), bits(want))
+
+
+def test_gpu_leaf_intersection_equals_eigen_golden(ctx, golden_dir):
+    """Each probe is one leaf (1..4 triangles) and one ray evaluated by the reference's Eigen expressions
+    (cpp/rtrayintersection.cpp:36-122 shapes): t, u, v, w per triangle and minCoeff's first-minimum row.
+    The same leaf as a one-mesh scene through rt_trace_rays must give that row and those bits."""
+    gold = np.load(os.path.join(golden_dir, "eigen_probe.npz"))
+    cnt = gold["mt_count"]
+    o = gold["mt_origin"].reshape(-1, 3)
+    d = gold["mt_dir"].reshape(-1, 3)
+    tris = gold["mt_tris"].reshape(-1, 3, 3)
+    starts = np.concatenate([[0], np.cumsum(cnt)[:-1]])
+    checked = hits = box_culled = 0
+    for b in range(cnt.size):
+        n, k0 = int(cnt[b]), int(starts[b])
+        if n > 4:
+            continue  # would be split into several leaves: row order is then not traversal order
+        c = np.ascontiguousarray(tris[k0:k0 + n][None])
+        k = np.full((1, n, 3), 0.5)
+        host = ra.HostScene([c], [k])
+        ctx.upload(host)
+        got = ctx.trace(o[b:b + 1], d[b:b + 1])
+        mesh, elem = host.map_prims(got["prim"])
+        t = gold["mt_t"][k0:k0 + n]
+        row = int(gold["mt_argmin"][b])
+        checked += 1
+        if np.isfinite(t[row]):
+            if elem[0] < 0:
+                # the reference tests the leaf's box first (intersect_BLAS) and so does the oracle: a probe
+                # whose ray misses the box by rounding is a miss for both
+                w = orc.Scene([c], [k]).trace(o[b:b + 1], d[b:b + 1])
+                assert w["elem"][0] < 0, b
+                box_culled += 1
+                continue
+            hits += 1
+            assert int(elem[0]) == row, b
+            assert bits(got["t"])[0] == bits(t[row:row + 1])[0], b
+            want_b = np.array([gold["mt_u"][k0 + row], gold["mt_v"][k0 + row], gold["mt_w"][k0 + row]])
+            assert np.array_equal(bits(got["bary"][0]), bits(want_b)), b
+        else:
+            assert elem[0] < 0, b
+    assert checked > 500 and hits > 100, (checked, hits, box_culled)
