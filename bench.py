@@ -11,7 +11,9 @@ BVH build and the upload happen before the timed region and are reported separat
 N > 1 is launched by torch.distributed.run, one rank per GPU; frames are sharded over ranks
 (frame f = step*N + rank, each at its own position of the reference's global RNG stream), with no
 data-path collective: only the barrier and the MAX-over-ranks of the elapsed time.
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0.  Besides the contract's fields it carries, under "aux" and never as part of
+`value`: the multi-frame driver's frames/s (BASELINE's second metric), the fp32 fast path with its measured
+tolerance, and for N > 1 one frame split into row bands over the ranks (strong scaling) with its gather.
 """
 import argparse
 import json
