@@ -128,8 +128,16 @@ struct rt_ctx {
     DevBuf<rtk32::Node32> nodes32;
     DevBuf<rtk32::Tlas32> tlas32;
     DevBuf<rtk32::Tri32> tris32;
-    DevBuf<rtk::FrameParams> frame_params;
-    rtk::FrameParams h_frame_params;  // host copy kept alive for the async upload
+    // per-frame camera block, two copies used alternately (a pipelined launch must not overwrite the
+    // host or device copy the previous launch may still be reading)
+    DevBuf<rtk::FrameParams> frame_params_buf[2];
+    rtk::FrameParams h_frame_params_buf[2];
+    int fp_idx = 0;
+    // rt_render_scene's pipelined launches: frame q+1 is enqueued before frame q is read back, so the
+    // frame buffers alternate (intensity/rgb always hold the LAST launch's output, prev_* the one before)
+    DevBuf<double> prev_intensity;
+    DevBuf<uint8_t> prev_rgb;
+    hipEvent_t out_done = nullptr, prev_out_done = nullptr;  // traversal kernel of the last / previous launch
     size_t n_nodes = 0, n_tlas = 0;
     double max_abs_coord = 0.0;  // largest |coordinate| of the uploaded scene (NaN/inf -> inf)
     int32_t stack_need = 1;
@@ -152,6 +160,8 @@ struct rt_ctx {
         uint64_t pos = 0;  // stream position the slot starts at
         int rows = 0, W = 0, spp = 0;
         hipEvent_t done = nullptr, t0 = nullptr, t1 = nullptr;
+        hipEvent_t read_done = nullptr;  // the traversal kernel that last read buf (refills wait for it)
+        bool read_pending = false;
         double host_ms = 0.0;
         // what d_states holds (survives `valid = false`): n states, `stride` words apart, from states_pos
         bool states_ok = false;
@@ -340,6 +350,8 @@ int fill_slot(rt_ctx* c, int k, uint64_t ahead, int rows, int W, int spp) {
     if ((rc = sl.d_states.ensure(size_t(pl.n) * rt::MT_N))) return rc;
     if ((rc = sl.d_end.ensure(rt::MT_N))) return rc;
     const double t0 = now_ms();
+    // a traversal kernel launched earlier may still be reading this slot's pairs
+    if (sl.read_pending) HIP_TRY(hipStreamWaitEvent(c->rng_stream, sl.read_done, 0));
     HIP_TRY(hipEventRecord(sl.t0, c->rng_stream));
     // Steady state of a frame loop: the other slot holds the stream states of a launch of the same
     // shape D words earlier -> every state advances by D in ONE launch (instead of one jump to the
@@ -642,7 +654,9 @@ rt_ctx* rt_create(int device) {
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->front_last_use, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->back_last_use, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->back_last_use, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->out_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->prev_out_done, hipEventDisableTiming) != hipSuccess) {
         g_err = "rt_create: copy stream / events";
         return nullptr;
     }
@@ -660,7 +674,8 @@ rt_ctx* rt_create(int device) {
         }
     for (auto& sl : c->slot)
         if (hipEventCreate(&sl.done) != hipSuccess || hipEventCreate(&sl.t0) != hipSuccess ||
-            hipEventCreate(&sl.t1) != hipSuccess) {
+            hipEventCreate(&sl.t1) != hipSuccess ||
+            hipEventCreateWithFlags(&sl.read_done, hipEventDisableTiming) != hipSuccess) {
             g_err = "rt_create: hipEventCreate failed";
             return nullptr;
         }
@@ -697,7 +712,8 @@ void rt_destroy(rt_ctx* c) {
     c->nodes32.release();
     c->tlas32.release();
     c->tris32.release();
-    c->frame_params.release();
+    c->frame_params_buf[0].release();
+    c->frame_params_buf[1].release();
     c->d_states.release();
     c->jitter.release();
     c->d_state.release();
@@ -711,6 +727,7 @@ void rt_destroy(rt_ctx* c) {
         if (sl.done) (void)hipEventDestroy(sl.done);
         if (sl.t0) (void)hipEventDestroy(sl.t0);
         if (sl.t1) (void)hipEventDestroy(sl.t1);
+        if (sl.read_done) (void)hipEventDestroy(sl.read_done);
     }
     c->intensity.release();
     c->hit_t.release();
@@ -743,6 +760,10 @@ void rt_destroy(rt_ctx* c) {
     c->back.leaf_ext.release();
     c->back.tris.release();
     c->back.colors.release();
+    if (c->out_done) (void)hipEventDestroy(c->out_done);
+    if (c->prev_out_done) (void)hipEventDestroy(c->prev_out_done);
+    c->prev_intensity.release();
+    c->prev_rgb.release();
     if (c->front_last_use) (void)hipEventDestroy(c->front_last_use);
     if (c->back_last_use) (void)hipEventDestroy(c->back_last_use);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
@@ -856,7 +877,16 @@ int rt_rng_state(rt_ctx* c, uint32_t* state624) {
 }
 
 /* ------------------------------------------------------------------ render */
-int rt_render(rt_ctx* c, const rt_render_params* p) {
+}  // extern "C"
+
+namespace {
+
+// rt_render.  `pipelined` (rt_render_scene only, plain MT19937 frames without per-sample outputs): the
+// launch is enqueued behind the previous one instead of waiting for it, so the GPU goes from frame to
+// frame without a gap while the host reads the previous frame back.  Everything a launch touches is
+// then either ordered on c->stream, double-buffered (frame buffers, camera block) or guarded by an
+// event (jitter slots).
+int render_impl(rt_ctx* c, const rt_render_params* p, bool pipelined) {
     if (!c || !p) return fail(RT_E_INVALID, "rt_render: null argument");
     if (!c->have_scene) return fail(RT_E_NO_SCENE, "rt_render: no scene uploaded");
     const int H = p->image_height, W = p->image_width, spp = p->samples;
@@ -872,11 +902,20 @@ int rt_render(rt_ctx* c, const rt_render_params* p) {
     const size_t n_pix = size_t(rows) * size_t(W);
     const size_t n_smp = n_pix * size_t(spp);
     HIP_TRY(hipSetDevice(c->device));
+    pipelined = pipelined && p->sampler == RT_SAMPLER_MT19937 && p->flags == 0;
     // outputs / jitter of the previous call may still be in flight
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (!pipelined) HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipStreamSynchronize(c->rng_stream));
 
     int rc;
+    // the previous launch's frame moves to prev_* (its kernel may still be writing it: only the
+    // pointers move); this launch writes the other pair
+    std::swap(c->intensity, c->prev_intensity);
+    std::swap(c->rgb, c->prev_rgb);
+    std::swap(c->out_done, c->prev_out_done);
+    c->fp_idx ^= 1;
+    DevBuf<rtk::FrameParams>& frame_params = c->frame_params_buf[c->fp_idx];
+    rtk::FrameParams& h_frame_params = c->h_frame_params_buf[c->fp_idx];
     if ((rc = c->intensity.ensure(n_pix))) return rc;
     if ((rc = c->rgb.ensure(n_pix * 3))) return rc;
     if (p->flags & RT_FLAG_HIT_IDS)
@@ -949,13 +988,13 @@ int rt_render(rt_ctx* c, const rt_render_params* p) {
         hipLaunchKernelGGL(rtk32::prep32_tris_kernel, dim3((unsigned)((c->n_tris + 255) / 256)), dim3(256), 0, c->stream,
                            c->tris.p, c->tris32.p, (long long)c->n_tris, ox, oy, oz);
         HIP_TRY(hipGetLastError());
-        if ((rc = c->frame_params.ensure(1))) return rc;
+        if ((rc = frame_params.ensure(1))) return rc;
         for (int i = 0; i < 3; ++i) {
-            c->h_frame_params.cam[i] = p->camera_center[i];
-            c->h_frame_params.p00[i] = p->pixel_00_center[i];
+            h_frame_params.cam[i] = p->camera_center[i];
+            h_frame_params.p00[i] = p->pixel_00_center[i];
         }
-        for (int i = 0; i < 6; ++i) c->h_frame_params.sp[i] = p->pixel_spacing[i];
-        HIP_TRY(hipMemcpyAsync(c->frame_params.p, &c->h_frame_params, sizeof(rtk::FrameParams), hipMemcpyHostToDevice,
+        for (int i = 0; i < 6; ++i) h_frame_params.sp[i] = p->pixel_spacing[i];
+        HIP_TRY(hipMemcpyAsync(frame_params.p, &h_frame_params, sizeof(rtk::FrameParams), hipMemcpyHostToDevice,
                                c->stream));
         rtk32::Packet32Args a;
         a.nodes = c->nodes32.p;
@@ -964,7 +1003,7 @@ int rt_render(rt_ctx* c, const rt_render_params* p) {
         a.leaf_ext = c->leaf_ext.p;
         a.tris = c->tris32.p;
         a.colors = c->colors.p;
-        a.fp = c->frame_params.p;
+        a.fp = frame_params.p;
         a.W = W;
         a.spp = spp;
         a.row0 = p->row_begin;
@@ -1005,15 +1044,15 @@ int rt_render(rt_ctx* c, const rt_render_params* p) {
         a.sc.leaf_ext = c->leaf_ext.p;
         a.sc.tris = c->cam_tris.p;
         a.sc.colors = c->colors.p;
-        if ((rc = c->frame_params.ensure(1))) return rc;
+        if ((rc = frame_params.ensure(1))) return rc;
         for (int i = 0; i < 3; ++i) {
-            c->h_frame_params.cam[i] = p->camera_center[i];
-            c->h_frame_params.p00[i] = p->pixel_00_center[i];
+            h_frame_params.cam[i] = p->camera_center[i];
+            h_frame_params.p00[i] = p->pixel_00_center[i];
         }
-        for (int i = 0; i < 6; ++i) c->h_frame_params.sp[i] = p->pixel_spacing[i];
-        HIP_TRY(hipMemcpyAsync(c->frame_params.p, &c->h_frame_params, sizeof(rtk::FrameParams), hipMemcpyHostToDevice,
+        for (int i = 0; i < 6; ++i) h_frame_params.sp[i] = p->pixel_spacing[i];
+        HIP_TRY(hipMemcpyAsync(frame_params.p, &h_frame_params, sizeof(rtk::FrameParams), hipMemcpyHostToDevice,
                                c->stream));
-        a.fp = c->frame_params.p;
+        a.fp = frame_params.p;
         a.W = W;
         a.spp = spp;
         a.row0 = p->row_begin;
@@ -1077,6 +1116,9 @@ int rt_render(rt_ctx* c, const rt_render_params* p) {
     }
     HIP_TRY(hipEventRecord(c->front_last_use, c->stream));  // rt_upload_scene waits for it before reusing the set
     c->front_used = true;
+    HIP_TRY(hipEventRecord(c->out_done, c->stream));
+    HIP_TRY(hipEventRecord(c->slot[use].read_done, c->stream));
+    c->slot[use].read_pending = true;
     c->timing_pending = true;
     c->out_rows = rows;
     c->out_w = W;
@@ -1094,8 +1136,8 @@ int rt_render(rt_ctx* c, const rt_render_params* p) {
                 if (delta >= uint64_t(n_smp) * 4u) next = start_pos + delta;
             }
             const int other = 1 - use;
-            // slot `other` was last read by the previous call's kernel, which has completed
-            // (stream synchronised on entry); its own jitter kernel is ordered on rng_stream.
+            // slot `other` was last read by the previous call's kernel: fill_slot makes rng_stream wait
+            // for it (read_done); the slot's own jitter kernel is ordered on rng_stream.
             if ((rc = fill_slot(c, other, next - c->pos, rows, W, spp))) return rc;
         } catch (const std::exception&) {
             c->slot[1 - use].valid = false;
@@ -1105,6 +1147,21 @@ int rt_render(rt_ctx* c, const rt_render_params* p) {
     }
     return RT_OK;
 }
+
+// rt_render_scene: the frame of the launch BEFORE the last one (pipelined launches), read back on the
+// copy stream while the last launch is still running
+int download_prev_rgb(rt_ctx* c, uint8_t* rgb, size_t n_bytes) {
+    HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->prev_out_done, 0));
+    HIP_TRY(hipMemcpyAsync(rgb, c->prev_rgb.p, n_bytes, hipMemcpyDeviceToHost, c->copy_stream));
+    HIP_TRY(hipStreamSynchronize(c->copy_stream));
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_render(rt_ctx* c, const rt_render_params* p) { return render_impl(c, p, false); }
 
 int rt_last_stats(const rt_ctx* cc, rt_stats* out) {
     if (!cc || !out) return fail(RT_E_INVALID, "rt_last_stats: null argument");
@@ -1337,6 +1394,9 @@ int rt_render_scene(int image_height, int image_width, int number_of_samples, co
     std::vector<uint8_t> rgb2[2] = {std::vector<uint8_t>(rgb_bytes), std::vector<uint8_t>(rgb_bytes)};
     std::future<void> writer;
     int wbuf = 0;
+    const bool pipeline = std::getenv("RT_NO_PIPELINE") == nullptr;  // (tuning knob)
+    bool have_prev = false;
+    int prev_t = 0, prev_cam = 0;
     top_up();
     int built_t = -1;
     for (int64_t q = 0; q < n_mine; ++q) {
@@ -1389,29 +1449,64 @@ int rt_render_scene(int image_height, int image_width, int number_of_samples, co
         p.row_end = image_height;
         p.sampler = RT_SAMPLER_MT19937;
         double t1 = now();
-        if ((rc = rt_render(c, &p))) return bail(rc);
+        // pipelined: this frame is enqueued behind the previous one; the previous frame is read back and
+        // written while this one renders
+        if ((rc = render_impl(c, &p, pipeline))) return bail(rc);
         t_render += now() - t1;
-        // the tree of the next timestep goes to the GPU (second buffer set, copy stream) while this
-        // timestep's last frame is still rendering
+        auto frame_path = [&](int tt, int cc) {
+            // cpp/rtmain.cpp:58-60: rtimage_<timestep>_cam<camera>.ppm, zero-based
+            return std::string(output_directory) + "/rtimage_" + std::to_string(tt) + "_cam" + std::to_string(cc) + ".ppm";
+        };
+        auto write_async = [&](const std::string& path, uint8_t* src) {
+            // like the reference, an unopenable file is reported and the job goes on
+            writer = std::async(std::launch::async, [path, image_width, image_height, src]() {
+                (void)rt_write_ppm(path.c_str(), image_width, image_height, src);
+            });
+            wbuf ^= 1;
+        };
+        if (pipeline) {
+            if (have_prev) {
+                t1 = now();
+                if (writer.valid()) writer.get();
+                uint8_t* dst = rgb2[wbuf].data();
+                if ((rc = download_prev_rgb(c, dst, rgb_bytes))) return bail(rc);
+                t_down += now() - t1;
+                t1 = now();
+                write_async(frame_path(prev_t, prev_cam), dst);
+                t_write += now() - t1;
+            }
+            have_prev = true;
+            prev_t = t;
+            prev_cam = cam;
+        }
+        // the tree of the next timestep becomes current (pointer swap; its helper thread has already
+        // copied it to the GPU) while this timestep's last frame is still rendering
         if (q + 1 < n_mine) {
             const int t_next = (int)(my_frames[q + 1] / n_cameras);
             if (t_next != built_t && (rc = advance_scene(t_next))) return rc;
         }
-        t1 = now();
-        if (writer.valid()) writer.get();  // previous file done (it was being written while this frame rendered)
+        if (!pipeline) {
+            t1 = now();
+            if (writer.valid()) writer.get();  // previous file done (it was being written while this frame rendered)
+            uint8_t* dst = rgb2[wbuf].data();
+            if ((rc = rt_download(c, nullptr, dst, nullptr, nullptr))) return bail(rc);
+            t_down += now() - t1;
+            t1 = now();
+            write_async(frame_path(t, cam), dst);
+            t_write += now() - t1;
+        }
+    }
+    if (pipeline && have_prev) {  // the last frame
+        if (writer.valid()) writer.get();
         uint8_t* dst = rgb2[wbuf].data();
-        if ((rc = rt_download(c, nullptr, dst, nullptr, nullptr))) return bail(rc);
-        t_down += now() - t1;
-        t1 = now();
-        // cpp/rtmain.cpp:58-60: rtimage_<timestep>_cam<camera>.ppm, zero-based
-        std::string path = std::string(output_directory) + "/rtimage_" + std::to_string(t) + "_cam" +
-                           std::to_string(cam) + ".ppm";
-        // like the reference, an unopenable file is reported and the job goes on
-        writer = std::async(std::launch::async, [path, image_width, image_height, dst]() {
-            (void)rt_write_ppm(path.c_str(), image_width, image_height, dst);
-        });
-        wbuf ^= 1;
-        t_write += now() - t1;
+        if ((rc = rt_download(c, nullptr, dst, nullptr, nullptr))) {
+            drain();
+            return rc;
+        }
+        (void)rt_write_ppm((std::string(output_directory) + "/rtimage_" + std::to_string(prev_t) + "_cam" +
+                            std::to_string(prev_cam) + ".ppm")
+                               .c_str(),
+                           image_width, image_height, dst);
     }
     if (writer.valid()) writer.get();
     if (timing)

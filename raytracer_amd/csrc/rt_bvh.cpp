@@ -220,11 +220,13 @@ Box range_box(const Elements& el, const int32_t* idx, int64_t first, int64_t cou
 
 // Decides axis and position; returns false only for count <= 2 (rtbvh.cpp:140).
 bool choose_split(const Elements& el, const int32_t* idx, int64_t first, int64_t count, const Box& parent,
-                  int& axis_out, double& pos_out, int64_t& fallbacks) {
+                  const Box* cb_known, int& axis_out, double& pos_out, int64_t& fallbacks) {
     if (count <= 2) return false;
     Box cb;
     cb.reset();
-    {
+    if (cb_known) {
+        cb = *cb_known;  // centroid bounds of this range, accumulated while the parent was partitioned
+    } else {
         const int64_t max_chunks = count < kParMin ? 1 : (count + kParChunk - 1) / kParChunk;
         std::vector<Box> part(static_cast<size_t>(max_chunks));
         int64_t nc = 0;
@@ -335,20 +337,67 @@ bool choose_split(const Elements& el, const int32_t* idx, int64_t first, int64_t
     return true;
 }
 
+// Boxes of the two sides of a partition, gathered during the partition pass itself instead of by
+// separate scans.  A union is a set of exact min/max, so the order of accumulation can only show in the
+// SIGN of a zero extreme (+0 and -0 compare equal; the serial scans keep the first one met): a box
+// with any component equal to zero is therefore not trusted (`ok` false) and recomputed by the
+// ordered scan, which keeps the tree bit-identical to the serial reference build.
+struct Sides {
+    Box box[2], cent[2];
+    bool box_ok[2] = {false, false}, cent_ok[2] = {false, false};
+};
+
+bool no_zero_component(const Box& b) {
+    for (int i = 0; i < 3; ++i)
+        if (b.mn[i] == 0.0 || b.mx[i] == 0.0) return false;
+    return true;
+}
+
 // Returns the left count, or -1 when the node must become a leaf.  The permutation of idx
 // happens even when the split is then rejected, exactly as in the reference.
 int64_t partition(const Elements& el, int32_t* idx, int64_t first, int64_t count, const Box& parent,
-                  int64_t& fallbacks) {
+                  const Box* cb_known, int64_t& fallbacks, Sides* sides) {
     int axis = 0;
     double pos = 0.0;
-    if (!choose_split(el, idx, first, count, parent, axis, pos, fallbacks)) return -1;
+    if (!choose_split(el, idx, first, count, parent, cb_known, axis, pos, fallbacks)) return -1;
     int64_t mid = first, end = first + count;
-    while (mid < end) {
-        if (el.cent[idx[mid]].c[axis] < pos) {
-            ++mid;
-        } else {
-            --end;
-            std::swap(idx[mid], idx[end]);
+    static const bool fold = std::getenv("RT_NO_FOLD") == nullptr;
+    if (fold && sides && count < kParMin) {
+        Box lb, rb, lc, rc;
+        lb.reset();
+        rb.reset();
+        lc.reset();
+        rc.reset();
+        while (mid < end) {
+            const int32_t e = idx[mid];
+            const Centroid& c = el.cent[e];
+            if (c.c[axis] < pos) {
+                lb.add_box(el.box[e]);
+                lc.add_point(c.c);
+                ++mid;
+            } else {
+                rb.add_box(el.box[e]);
+                rc.add_point(c.c);
+                --end;
+                std::swap(idx[mid], idx[end]);
+            }
+        }
+        sides->box[0] = lb;
+        sides->box[1] = rb;
+        sides->cent[0] = lc;
+        sides->cent[1] = rc;
+        sides->box_ok[0] = no_zero_component(lb);
+        sides->box_ok[1] = no_zero_component(rb);
+        sides->cent_ok[0] = no_zero_component(lc);
+        sides->cent_ok[1] = no_zero_component(rc);
+    } else {
+        while (mid < end) {
+            if (el.cent[idx[mid]].c[axis] < pos) {
+                ++mid;
+            } else {
+                --end;
+                std::swap(idx[mid], idx[end]);
+            }
         }
     }
     const int64_t nl = mid - first;
@@ -360,6 +409,8 @@ struct Task {
     int64_t count;
     int32_t node;
     int64_t first;
+    bool cent_ok = false;  // `cent` holds the centroid bounds of the range
+    Box cent;
 };
 
 void set_box(HostNode& n, const Box& b) {
@@ -386,7 +437,13 @@ struct Deferred {
 void expand(std::vector<HostNode>& nodes, const Elements& el, int32_t* idx, int max_leaf, int64_t& fallbacks,
             int64_t defer_below, std::vector<Deferred>* deferred) {
     std::vector<Task> stack;
-    stack.push_back({nodes[0].count, 0, nodes[0].first});
+    {
+        Task t0{};
+        t0.count = nodes[0].count;
+        t0.node = 0;
+        t0.first = nodes[0].first;
+        stack.push_back(t0);
+    }
     while (!stack.empty()) {
         const Task t = stack.back();
         stack.pop_back();
@@ -396,18 +453,19 @@ void expand(std::vector<HostNode>& nodes, const Elements& el, int32_t* idx, int 
             continue;
         }
         const Box parent = get_box(nodes[t.node]);
-        const int64_t nl = partition(el, idx, t.first, t.count, parent, fallbacks);
+        Sides sides;
+        const int64_t nl = partition(el, idx, t.first, t.count, parent, t.cent_ok ? &t.cent : nullptr, fallbacks, &sides);
         if (nl < 0) continue;  // stays a leaf with t.count elements (possibly > max_leaf)
         if (nodes.size() + 2 > static_cast<size_t>(std::numeric_limits<int32_t>::max()))
             throw std::runtime_error("BVH has more than 2^31 nodes");
         const int32_t left = static_cast<int32_t>(nodes.size());
         const int64_t nr = t.count - nl;
         HostNode l{}, r{};
-        set_box(l, range_box(el, idx, t.first, nl));
+        set_box(l, sides.box_ok[0] ? sides.box[0] : range_box(el, idx, t.first, nl));
         l.count = nl;
         l.left = -1;
         l.first = static_cast<int32_t>(t.first);
-        set_box(r, range_box(el, idx, t.first + nl, nr));
+        set_box(r, sides.box_ok[1] ? sides.box[1] : range_box(el, idx, t.first + nl, nr));
         r.count = nr;
         r.left = -1;
         r.first = static_cast<int32_t>(t.first + nl);
@@ -415,8 +473,19 @@ void expand(std::vector<HostNode>& nodes, const Elements& el, int32_t* idx, int 
         nodes.push_back(r);
         nodes[t.node].left = left;
         nodes[t.node].count = 0;
-        stack.push_back({nr, left + 1, t.first + nl});
-        stack.push_back({nl, left, t.first});
+        Task tr{}, tl{};
+        tr.count = nr;
+        tr.node = left + 1;
+        tr.first = t.first + nl;
+        tr.cent_ok = sides.cent_ok[1];
+        tr.cent = sides.cent[1];
+        tl.count = nl;
+        tl.node = left;
+        tl.first = t.first;
+        tl.cent_ok = sides.cent_ok[0];
+        tl.cent = sides.cent[0];
+        stack.push_back(tr);
+        stack.push_back(tl);
     }
 }
 
