@@ -17,14 +17,14 @@ def assert_same_tree(coords, colors, timestep=0):
     to, tp = o.tlas(), p.tlas()
     for k in ("blas_count", "left", "min_blas_idx"):
         assert np.array_equal(to[k], tp[k]), k
-    assert np.array_equal(to["boxes"], tp["boxes"])
+    assert np.array_equal(to["boxes"].view(np.uint64), tp["boxes"].view(np.uint64))  # bit for bit (sign of zero too)
     total = 0
     for s in range(o.n_slots):
         so, sp = o.slot(s), p.slot(s)
         assert so["mesh"] == sp["mesh"]
         for k in ("left", "count", "min_idx", "indices"):
             assert np.array_equal(so[k], sp[k]), (s, k)
-        assert np.array_equal(so["boxes"], sp["boxes"]), s
+        assert np.array_equal(so["boxes"].view(np.uint64), sp["boxes"].view(np.uint64)), s  # bit for bit
         assert sp["tri_base"] == total
         total += sp["indices"].size
         # prim tables agree with the permutation
@@ -162,3 +162,18 @@ def test_large_meshes_take_the_parallel_build_and_match_the_serial_oracle():
     c2[0, 1000:2000] = c2[0, :1000]
     c3, k3 = meshgen.plate(260, x0=50.0, y0=-3.0)
     assert_same_tree([c2, c3], [k2, k3])
+
+
+def test_signed_zero_extremes_follow_the_serial_scan_order():
+    """Box extremes are exact min/max, so only the SIGN of a zero extreme can depend on the order in which
+    triangles are visited (+0 == -0).  The builder gathers child boxes while it partitions (another order than
+    the reference's range scan) and must fall back to the ordered scan for zero extremes: meshes full of +0/-0
+    coordinates on box faces must still match the oracle's serial build bit for bit."""
+    rng = np.random.default_rng(12)
+    for n in (20, 150):
+        c, k = meshgen.plate(n, side=8.0, amp=0.0, z0=0.0)   # flat sheet in the z = 0 plane, x/y grid lines at 0
+        c = c.copy()
+        flip = rng.random(c.shape) < 0.5
+        c[(c == 0.0) & flip] = -0.0
+        assert (np.signbit(c) & (c == 0.0)).any() and (~np.signbit(c) & (c == 0.0)).any()
+        assert_same_tree([c], [k])
