@@ -1,12 +1,17 @@
 // rt_kernels.hip.hpp -- gfx950 device code of the render hot path (included by rt_api.hip).
 //
 // Kernels
+//   prep_nodes_kernel / prep_tris_kernel   per-frame camera-relative records (everything that depends
+//                      only on the camera centre, computed once per frame with the reference's operations)
+//   render_packet_kernel   THE hot kernel: ray generation + wave-packet TLAS/BLAS traversal on the scalar
+//                      unit + Moller-Trumbore + shading + in-order sample accumulation + luma/quantise
+//                      (reference: cpp/rtrender.cpp:13-67, cpp/rtrayintersection.cpp:36-228)
+//   render_kernel      the same per lane (LDS or global stack): trees deeper than the packet stack
+//   trace_kernel       the same traversal for caller-supplied rays (rt_trace_rays, test seam)
+//   mt_jump_kernel / mt_jump_tree_kernel / mt_jump_all_kernel   GF(2) jump-ahead of MT19937 states
 //   mt_jitter_kernel   MT19937 words -> random_double()-0.5 values, one wave per jump-ahead
 //                      stream (reference: cpp/rtmathutils.h:15-19, cpp/rtrender.cpp:53)
-//   render_kernel      ray generation + TLAS/BLAS traversal + Moller-Trumbore + shading +
-//                      in-order sample accumulation + luma/quantise
-//                      (reference: cpp/rtrender.cpp:13-67, cpp/rtrayintersection.cpp:36-228)
-//   trace_kernel       the same traversal for caller-supplied rays (test seam)
+//   (the fp32 fast path lives in rt_kernels_fp32.hip.hpp)
 //
 // Numerics contract (parity with the reference's x86-64 -O2 build): IEEE binary64, no FMA
 // contraction (this TU is compiled with -ffp-contract=off), true division and sqrt, every
