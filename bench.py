@@ -391,6 +391,21 @@ def main():
             del exact, fast, d
         except Exception as e:  # the fast path must never take the bench line down
             fp32 = {"error": str(e)}
+        # counter-based fast sampler (RT_SAMPLER_PHILOX): other samples than the reference, reported separately
+        philox = None
+        try:
+            t_ph = []
+            for _ in range(3):
+                ctx.sync()
+                t1 = time.perf_counter()
+                frame(0, philox=True)
+                ctx.sync()
+                t_ph.append(time.perf_counter() - t1)
+            philox = {"ms_per_frame": float(np.mean(t_ph[1:])) * 1e3,
+                      "mrays_per_s": rays_per_frame / float(np.mean(t_ph[1:])) / 1e6,
+                      "note": "sampler kernel + traversal, no look-ahead needed; not the reference's samples"}
+        except Exception as e:
+            philox = {"error": str(e)}
         cpu = None
         if args.cpu_rays > 0:
             frame(0)
@@ -432,7 +447,7 @@ def main():
                     "upload_s": upload_s, "stack_need": int(host.info.stack_need),
                     "download_frame_ms": dl_frame_ms, "download_hit_ids_ms": dl_ids_ms,
                     "kernel_ms_timed_step": kernel_ms[-1] if kernel_ms else None,
-                    "multiframe": multiframe, "fp32_fast_path": fp32, "single_frame_banded": banded},
+                    "multiframe": multiframe, "fp32_fast_path": fp32, "philox_sampler": philox, "single_frame_banded": banded},
         }
     if dist is not None:
         dist.barrier()

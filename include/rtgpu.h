@@ -122,6 +122,8 @@ int rt_mt19937_stream_states(uint32_t seed, uint64_t base_position, uint64_t str
 /* ------------------------------------------------------------------ */
 #define RT_SAMPLER_MT19937 0  /* reference stream from the context's position */
 #define RT_SAMPLER_EXPLICIT 1 /* caller supplies the (ox, oy) offsets */
+#define RT_SAMPLER_PHILOX 2   /* counter-based FAST sampler, NOT the reference's stream (reported separately):
+                                 sample s of the stream (position/4) = Philox4x32-10({s,0,0},{seed,0}); no state */
 
 #define RT_FLAG_HIT_IDS 1u  /* keep per-sample prim ids (int32, -1 = miss) */
 #define RT_FLAG_COUNTERS 2u /* count nodes/triangles visited (slower; for the roofline model) */

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "librtgpu.so")
 RT_OK = 0
 RT_SAMPLER_MT19937 = 0
 RT_SAMPLER_EXPLICIT = 1
+RT_SAMPLER_PHILOX = 2
 RT_FLAG_HIT_IDS = 1
 RT_FLAG_COUNTERS = 2
 RT_FLAG_HIT_T = 4

@@ -134,8 +134,9 @@ class Context:
 
     # ---- render ----
     def render(self, cam, p00, spacing, H, W, spp, *, rows=None, jitter=None, hit_ids=False, hit_t=False,
-               counters=False, fp32=False):
-        """fp32=True selects the fp32 FAST PATH (RT_FLAG_FP32): not bit-exact, reported separately."""
+               counters=False, fp32=False, philox=False):
+        """fp32=True selects the fp32 FAST PATH (RT_FLAG_FP32): not bit-exact, reported separately.
+        philox=True selects the counter-based fast sampler (RT_SAMPLER_PHILOX): other samples than the reference."""
         p = L.RenderParams()
         p.camera_center[:] = list(L.f64(cam, 3))
         p.pixel_00_center[:] = list(L.f64(p00, 3))
@@ -153,7 +154,7 @@ class Context:
             p.sampler = L.RT_SAMPLER_EXPLICIT
             p.jitter = keep.ctypes.data
         else:
-            p.sampler = L.RT_SAMPLER_MT19937
+            p.sampler = L.RT_SAMPLER_PHILOX if philox else L.RT_SAMPLER_MT19937
         L.check(lib.rt_render(self.h, C.byref(p)), "rt_render")
         self._shape = (p.row_end - p.row_begin, int(W), int(spp))
         self._flags = p.flags

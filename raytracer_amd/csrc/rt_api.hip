@@ -893,7 +893,7 @@ int render_impl(rt_ctx* c, const rt_render_params* p, bool pipelined) {
     if (H < 1 || W < 1 || spp < 1) return fail(RT_E_INVALID, "rt_render: image size and samples must be >= 1");
     if (p->row_begin < 0 || p->row_end > H || p->row_begin >= p->row_end)
         return fail(RT_E_INVALID, "rt_render: bad row range");
-    if (p->sampler != RT_SAMPLER_MT19937 && p->sampler != RT_SAMPLER_EXPLICIT)
+    if (p->sampler != RT_SAMPLER_MT19937 && p->sampler != RT_SAMPLER_EXPLICIT && p->sampler != RT_SAMPLER_PHILOX)
         return fail(RT_E_INVALID, "rt_render: unknown sampler");
     if (p->sampler == RT_SAMPLER_EXPLICIT && !p->jitter)
         return fail(RT_E_INVALID, "rt_render: RT_SAMPLER_EXPLICIT needs a jitter array");
@@ -937,6 +937,21 @@ int render_impl(rt_ctx* c, const rt_render_params* p, bool pipelined) {
         if ((rc = c->slot[0].buf.ensure(n_smp * 2))) return rc;
         HIP_TRY(hipMemcpyAsync(c->slot[0].buf.p, p->jitter, n_smp * 2 * sizeof(double), hipMemcpyHostToDevice,
                                c->stream));
+    } else if (p->sampler == RT_SAMPLER_PHILOX) {
+        // counter-based fast sampler: one fully parallel kernel on the traversal stream, keyed by the
+        // context's seed and the global sample number (stream position / 4)
+        use = 0;
+        c->slot[0].valid = false;
+        if ((rc = c->slot[0].buf.ensure(n_smp * 2))) return rc;
+        hipLaunchKernelGGL(rtk::philox_jitter_kernel, dim3((unsigned)((n_smp + 255) / 256)), dim3(256), 0, c->stream,
+                           c->slot[0].buf.p, (unsigned long long)n_smp, (unsigned long long)(c->pos / 4u), c->seed, 0u);
+        HIP_TRY(hipGetLastError());
+        try {  // the MT19937 state follows the position, so the samplers can be mixed within one stream
+            if ((rc = dev_jump(c, c->d_state.p, c->d_state.p, uint64_t(n_smp) * 4u))) return rc;
+        } catch (const std::exception& e) {
+            return fail(RT_E_INVALID, std::string("rt_render: sampler: ") + e.what());
+        }
+        c->pos += uint64_t(n_smp) * 4u;
     } else {
         try {
             use = -1;

@@ -1168,6 +1168,52 @@ __global__ __launch_bounds__(JUMP_THREADS) void mt_jump_tree_kernel(uint32_t* st
     mt_jump_block(states + srci * 624, states + dsti * 624, poly, blockIdx.y, jump_x);
 }
 
+// Counter-based FAST sampler (RT_SAMPLER_PHILOX; not the reference's stream, reported separately):
+// sample s of the global stream gets Philox4x32-10(counter = {s, 0, 0}, key = {seed, 0}) (Salmon et al.,
+// SC'11); the four words become the (ox, oy) pair with the same two-words-per-double conversion as
+// generate_canonical.  No state, no jump-ahead: any band / frame / GPU computes its samples directly.
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                              uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0;
+        c1 = n1;
+        c2 = n2;
+        c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0;
+    out[1] = c1;
+    out[2] = c2;
+    out[3] = c3;
+}
+
+__global__ __launch_bounds__(256) void philox_jitter_kernel(double* __restrict__ out, const unsigned long long n_samples,
+                                                            const unsigned long long sample_base, const uint32_t key0,
+                                                            const uint32_t key1) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_samples) return;
+    const unsigned long long sidx = sample_base + i;
+    uint32_t w[4];
+    philox4x32_10((uint32_t)sidx, (uint32_t)(sidx >> 32), 0u, 0u, key0, key1, w);
+    d2 r;
+    {
+        double v = ((double)w[0] + (double)w[1] * 4294967296.0) / 18446744073709551616.0;
+        if (v >= 1.0) v = 0x1.fffffffffffffp-1;
+        r.x = v - 0.5;
+    }
+    {
+        double v = ((double)w[2] + (double)w[3] * 4294967296.0) / 18446744073709551616.0;
+        if (v >= 1.0) v = 0x1.fffffffffffffp-1;
+        r.y = v - 0.5;
+    }
+    __builtin_nontemporal_store(r, reinterpret_cast<d2*>(out) + i);
+}
+
 // every stream state advanced by the same distance: dst[i] = g(A) src[i], grid (n, JUMP_PARTS); dst zeroed
 // beforehand.  A frame loop with a constant distance between frames needs only this one launch per frame
 // instead of the doubling tree.
