@@ -249,9 +249,11 @@ StreamPlan plan_streams(int rows, int W, int spp) {
     // 3.2 ns/word, and one jump costs ~1.2 us of the whole GPU.  The traversal kernel needs ~0.015 ns per
     // word, so ~450 streams already keep the jitter kernel shorter than half the traversal it hides
     // behind, whatever the frame size; more streams only add jump work.  Up to 512 streams, none shorter
-    // than 2^16 words; strides are whole regenerations, not whole rows.
+    // than 2^16 words (2^13 for the first 64); strides are whole regenerations, not whole rows.
     const uint64_t words = uint64_t(rows) * uint64_t(W) * uint64_t(spp) * 4u;
     uint64_t target = std::min<uint64_t>(512, std::max<uint64_t>(1, words >> 16));
+    // small frames are bound by the latency of one wave walking its stream: allow up to 64 shorter streams
+    target = std::max<uint64_t>(target, std::min<uint64_t>(64, words >> 13));
     if (const char* e = std::getenv("RT_JITTER_STREAMS")) target = (uint64_t)std::max(1, std::atoi(e));
     uint64_t stride = (words + target - 1) / target;
     stride = (stride + 623) / 624 * 624;
