@@ -204,6 +204,12 @@ int rt_render_scene(int image_height, int image_width, int number_of_samples, co
  * f = t*n_cameras + c it renders (f % world == rank) and the position of each in the global RNG
  * stream (stream_base + f*frame_words).  Returns the number of frames written (<= capacity), or a
  * negative error.  frames/positions may be NULL to query the count only. */
+/* Position (in 32-bit words) of the never-reseeded stream rt_render_scene draws from on `device`: the
+ * reference's process-global `static std::mt19937 generator` (cpp/rtmathutils.h:16) persists across
+ * render_scene calls, and so does this.  0 before the first call.  Test seam; the reference's generator
+ * is not observable. */
+uint64_t rt_driver_stream_position(int device);
+
 int64_t rt_shard_frames(int timestep_count, int n_cameras, int rank, int world, uint64_t stream_base,
                         uint64_t frame_words, int64_t capacity, int64_t *frames, uint64_t *positions);
 

@@ -79,6 +79,7 @@ _PROTOS = {
     "rt_render_scene": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int, C.POINTER(_VP),
                                   C.POINTER(_VP), _VP, C.c_int, _VP, _VP, _VP, C.c_int, C.c_int, C.c_int]),
     "rt_shard_frames": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_int64, _VP, _VP]),
+    "rt_driver_stream_position": (C.c_uint64, [C.c_int]),
     "rt_shard_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.POINTER(C.c_int),
                                 C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
     "rt_write_ppm": (C.c_int, [C.c_char_p, C.c_int, C.c_int, _VP]),

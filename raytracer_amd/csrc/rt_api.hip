@@ -1311,6 +1311,12 @@ int64_t rt_shard_frames(int timestep_count, int n_cameras, int rank, int world, 
     return n;
 }
 
+uint64_t rt_driver_stream_position(int device) {
+    if (device < 0 || device >= 64) return 0;
+    std::lock_guard<std::mutex> lk(g_global_mu);
+    return g_global_ctx[device] ? g_global_ctx[device]->pos : 0;
+}
+
 int rt_shard_rows(int image_height, int image_width, int number_of_samples, int rank, int world, uint64_t frame_base,
                   int* row_begin, int* row_end, uint64_t* stream_position) {
     if (image_height < 1 || image_width < 1 || number_of_samples < 1 || world < 1 || rank < 0 || rank >= world ||

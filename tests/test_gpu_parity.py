@@ -480,3 +480,40 @@ def test_gpu_leaf_intersection_equals_eigen_golden(ctx, golden_dir):
         else:
             assert elem[0] < 0, b
     assert checked > 500 and hits > 100, (checked, hits, box_culled)
+
+
+def test_long_sequence_through_the_pipelined_driver(ctx, tmp_path):
+    """14 timesteps x 2 cameras through rt_render_scene: more timesteps than staged device buffer sets, so the
+    helper-thread uploads, the pointer swaps, the alternating frame buffers and the jitter slots are all reused
+    several times while frames are in flight.  Every file must be the oracle's frame of the one continuous
+    stream."""
+    T = 14
+    c, k = meshgen.plate(40, T=T, sway=0.15)
+    c2, k2 = meshgen.uv_sphere(14, 18, radius=1.2, center=(0.8, -0.4, -3.0), T=T)
+    c2 = c2 + np.linspace(0.0, 0.5, T)[:, None, None, None]  # the sphere drifts
+    c3, k3 = meshgen.random_soup(400, seed=3, T=T)
+    H, W, spp = 96, 128, 6
+    cams = [meshgen.camera_arrays(W, H), meshgen.camera_arrays(W, H, center=(0.6, 0.3, 0.4), target=(0, 0, -2), fov=70)]
+    sc = ra.Scene()
+    for cc_, kk_ in ((c, k), (c2, k2), (c3, k3)):
+        sc.add_mesh(np.ascontiguousarray(cc_), None, None, np.ascontiguousarray(kk_), T)
+    for cam in cams:
+        sc.add_camera(*cam)
+    out = tmp_path / "seq"
+    out.mkdir()
+    from raytracer_amd import _lib as L
+    base = int(L.lib.rt_driver_stream_position(0))  # the driver's stream persists across calls, like the reference's
+    ra.render_scene(H, W, sc, spp, out)
+    assert len(os.listdir(out)) == 2 * T
+    assert int(L.lib.rt_driver_stream_position(0)) == base + 2 * T * H * W * spp * 4
+    frame_words = H * W * spp * 4
+    hdr = f"P6\n{W} {H}\n255\n".encode()
+    meshes = [np.ascontiguousarray(c), np.ascontiguousarray(c2), np.ascontiguousarray(c3)]
+    cols = [k, k2, k3]
+    g = orc.Rng()
+    g.discard(base)
+    for t in range(T):
+        osc = orc.Scene(meshes, cols, t)
+        for ci, cam in enumerate(cams):
+            want = osc.render(*cam, H, W, spp, rng=g, want_hits=False)
+            assert (out / f"rtimage_{t}_cam{ci}.ppm").read_bytes() == hdr + want["rgb"].tobytes(), (t, ci)
