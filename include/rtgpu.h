@@ -191,7 +191,7 @@ int rt_trace_rays(rt_ctx *ctx, int64_t n, const double *origins, const double *d
 /* <dir>/rtimage_<t>_cam<c>.ppm, printing the reference's stdout lines.*/
 /* The sampler stream is process-global and never reseeded, like the   */
 /* reference's static generator.                                       */
-/* rank/world shard frames f = t*n_cameras + c with f % world == rank  */
+/* rank/world shard the frames f = t*n_cameras + c (see rt_shard_frames) */
 /* (no collective; every rank seeks the stream to its frame).          */
 /* ------------------------------------------------------------------ */
 int rt_render_scene(int image_height, int image_width, int number_of_samples, const char *output_directory,
@@ -200,16 +200,17 @@ int rt_render_scene(int image_height, int image_width, int number_of_samples, co
                     const double *camera_centers, const double *pixel_00_centers,
                     const double *pixel_spacings, int device, int rank, int world);
 
-/* Host-only: the frame schedule rt_render_scene uses.  For rank `rank` of `world` it lists the frames
- * f = t*n_cameras + c it renders (f % world == rank) and the position of each in the global RNG
- * stream (stream_base + f*frame_words).  Returns the number of frames written (<= capacity), or a
- * negative error.  frames/positions may be NULL to query the count only. */
 /* Position (in 32-bit words) of the never-reseeded stream rt_render_scene draws from on `device`: the
  * reference's process-global `static std::mt19937 generator` (cpp/rtmathutils.h:16) persists across
  * render_scene calls, and so does this.  0 before the first call.  Test seam; the reference's generator
  * is not observable. */
 uint64_t rt_driver_stream_position(int device);
 
+/* Host-only: the frame schedule rt_render_scene uses.  For rank `rank` of `world` it lists the frames
+ * f = t*n_cameras + c it renders -- whole timesteps, t % world == rank, when timestep_count >= world (one
+ * host BVH build per timestep, on one rank), else single frames, f % world == rank -- and the position of
+ * each in the global RNG stream (stream_base + f*frame_words).  Returns the number of frames written (<= capacity), or a
+ * negative error.  frames/positions may be NULL to query the count only. */
 int64_t rt_shard_frames(int timestep_count, int n_cameras, int rank, int world, uint64_t stream_base,
                         uint64_t frame_words, int64_t capacity, int64_t *frames, uint64_t *positions);
 

@@ -1302,8 +1302,14 @@ int64_t rt_shard_frames(int timestep_count, int n_cameras, int rank, int world, 
     if (timestep_count < 0 || n_cameras < 0 || world < 1 || rank < 0 || rank >= world)
         return fail(RT_E_INVALID, "rt_shard_frames: bad counts");
     const int64_t total = int64_t(timestep_count) * n_cameras;
+    // Whole timesteps go to one rank when there are enough of them (t % world == rank): the per-timestep host
+    // BVH build is then done once, not once per camera on different ranks.  With fewer timesteps than ranks
+    // single frames are dealt out instead (f % world == rank).
+    const bool by_timestep = timestep_count >= world && n_cameras > 0;
     int64_t n = 0;
-    for (int64_t f = rank; f < total; f += world) {
+    for (int64_t f = 0; f < total; ++f) {
+        const int64_t owner = by_timestep ? (f / n_cameras) % world : f % world;
+        if (owner != rank) continue;
         if (frames && n < capacity) frames[n] = f;
         if (positions && n < capacity) positions[n] = stream_base + uint64_t(f) * frame_words;
         ++n;

@@ -67,7 +67,8 @@ def test_two_ranks_cover_all_frames_once():
         assert p.exitcode == 0
     assert frames == list(range(T * C))
     assert ok == 1
-    assert pos0 == [f * frame_words for f in range(0, T * C, world)]
+    # T >= world: whole timesteps are dealt out (t % world == rank), so rank 0 holds t = 0, 2, 4 with all cameras
+    assert pos0 == [(t * C + c) * frame_words for t in range(0, T, world) for c in range(C)]
 
 
 def test_schedule_edge_cases():
@@ -77,8 +78,16 @@ def test_schedule_edge_cases():
     assert len(f) == 0
     f, p = ra.shard_frames(3, 1, 3, 4, stream_base=100, frame_words=7)
     assert len(f) == 0
-    f, p = ra.shard_frames(3, 2, 1, 4, stream_base=100, frame_words=7)
+    f, p = ra.shard_frames(3, 2, 1, 4, stream_base=100, frame_words=7)  # fewer timesteps than ranks: by frame
     assert f.tolist() == [1, 5] and p.tolist() == [107, 135]
+    f, p = ra.shard_frames(5, 2, 1, 4, stream_base=100, frame_words=7)  # enough timesteps: by timestep
+    assert f.tolist() == [2, 3] and p.tolist() == [114, 121]
+    for T, C, world in [(5, 3, 2), (8, 2, 8), (3, 2, 4), (100, 1, 8), (7, 2, 3)]:
+        got = sorted(int(x) for r in range(world) for x in ra.shard_frames(T, C, r, world)[0])
+        assert got == list(range(T * C))  # every frame exactly once
+        if T >= world:
+            for r in range(world):
+                assert all((int(x) // C) % world == r for x in ra.shard_frames(T, C, r, world)[0])
 
 
 # ----------------------------------------------------------------------------------------------
