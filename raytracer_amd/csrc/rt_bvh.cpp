@@ -203,7 +203,13 @@ void for_chunks(int64_t first, int64_t count, int64_t& n_chunks, const F& fn) {
 }
 
 Box range_box(const Elements& el, const int32_t* idx, int64_t first, int64_t count) {
-    const int64_t max_chunks = count < kParMin ? 1 : (count + kParChunk - 1) / kParChunk;
+    if (count < kParMin) {
+        Box b;
+        b.reset();
+        for (int64_t i = first; i < first + count; ++i) b.add_box(el.box[idx[i]]);
+        return b;
+    }
+    const int64_t max_chunks = (count + kParChunk - 1) / kParChunk;
     std::vector<Box> part(static_cast<size_t>(max_chunks));
     int64_t nc = 0;
     for_chunks(first, count, nc, [&](int64_t c, int64_t lo, int64_t hi) {
@@ -226,8 +232,10 @@ bool choose_split(const Elements& el, const int32_t* idx, int64_t first, int64_t
     cb.reset();
     if (cb_known) {
         cb = *cb_known;  // centroid bounds of this range, accumulated while the parent was partitioned
+    } else if (count < kParMin) {
+        for (int64_t i = first; i < first + count; ++i) cb.add_point(el.cent[idx[i]].c);
     } else {
-        const int64_t max_chunks = count < kParMin ? 1 : (count + kParChunk - 1) / kParChunk;
+        const int64_t max_chunks = (count + kParChunk - 1) / kParChunk;
         std::vector<Box> part(static_cast<size_t>(max_chunks));
         int64_t nc = 0;
         for_chunks(first, count, nc, [&](int64_t c, int64_t lo, int64_t hi) {
@@ -263,12 +271,21 @@ bool choose_split(const Elements& el, const int32_t* idx, int64_t first, int64_t
     }
     const double inv_ext = 1.0 / ext;
     const double cmin = cb.mn[axis];
-    {
+    if (count < kParMin) {  // the common case: straight into the bins, nothing on the heap
+        for (int64_t i = first; i < first + count; ++i) {
+            const int32_t e = idx[i];
+            double t = (el.cent[e].c[axis] - cmin) * inv_ext;
+            int b = static_cast<int>(t * kBins);
+            if (b == kBins) b = kBins - 1;
+            bin_cnt[b]++;
+            bin_box[b].add_box(el.box[e]);
+        }
+    } else {
         struct Bins {
             Box box[kBins];
             uint32_t cnt[kBins];
         };
-        const int64_t max_chunks = count < kParMin ? 1 : (count + kParChunk - 1) / kParChunk;
+        const int64_t max_chunks = (count + kParChunk - 1) / kParChunk;
         std::vector<Bins> part(static_cast<size_t>(max_chunks));
         int64_t nc = 0;
         for_chunks(first, count, nc, [&](int64_t c, int64_t lo, int64_t hi) {
@@ -294,33 +311,30 @@ bool choose_split(const Elements& el, const int32_t* idx, int64_t first, int64_t
             }
     }
 
-    uint32_t lcnt[kBins], rcnt[kBins];
-    Box lbox[kBins], rbox[kBins];
+    // suffix (right-side) areas and counts first, then one forward sweep with the running left box:
+    // the same unions in the same order as prefix / suffix arrays of boxes, without the copies
+    double rarea[kBins];
+    uint32_t rcnt[kBins];
     Box run;
     run.reset();
     uint32_t n = 0;
-    for (int b = 0; b < kBins; ++b) {
-        if (bin_cnt[b] > 0) run.add_box(bin_box[b]);
-        n += bin_cnt[b];
-        lbox[b] = run;
-        lcnt[b] = n;
-    }
-    run.reset();
-    n = 0;
     for (int b = kBins - 1; b >= 0; --b) {
         if (bin_cnt[b] > 0) run.add_box(bin_box[b]);
         n += bin_cnt[b];
-        rbox[b] = run;
+        rarea[b] = run.area();
         rcnt[b] = n;
     }
-
     double best = kInf;
     int best_bin = -1;
     const double ap = parent.area();
+    run.reset();
+    n = 0;
     for (int b = 0; b < kBins - 1; ++b) {
-        const uint32_t nl = lcnt[b], nr = rcnt[b + 1];
+        if (bin_cnt[b] > 0) run.add_box(bin_box[b]);
+        n += bin_cnt[b];
+        const uint32_t nl = n, nr = rcnt[b + 1];
         if (nl == 0 || nr == 0) continue;
-        const double al = lbox[b].area(), ar = rbox[b + 1].area();
+        const double al = run.area(), ar = rarea[b + 1];
         const double cost = 1.0 + 2.0 * (al / ap * nl + ar / ap * nr);
         if (cost < best) {
             best = cost;
