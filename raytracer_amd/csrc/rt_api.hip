@@ -245,13 +245,13 @@ struct StreamPlan {
 
 StreamPlan plan_streams(int rows, int W, int spp) {
     StreamPlan p;
-    // One wave per stream.  Measured: a stream regenerates 624 words in ~2 us (LDS-latency bound), i.e.
-    // 3.2 ns/word, and one jump costs ~1.2 us of the whole GPU.  The traversal kernel needs ~0.015 ns per
-    // word, so ~450 streams already keep the jitter kernel shorter than half the traversal it hides
-    // behind, whatever the frame size; more streams only add jump work.  Up to 512 streams, none shorter
-    // than 2^16 words (2^13 for the first 64); strides are whole regenerations, not whole rows.
+    // One workgroup per stream.  Measured: a stream regenerates 624 words in ~1.2 us (a chain of dependent
+    // LDS round trips), i.e. ~1.9 ns/word, and one jump costs ~1.2 us of the whole GPU.  The traversal kernel
+    // needs ~0.015 ns per word, so ~250 streams keep the jitter kernel shorter than half the traversal it
+    // hides behind, whatever the frame size; more streams only add jump work.  Up to 256 streams, none
+    // shorter than 2^16 words (2^13 for the first 64); strides are whole regenerations, not whole rows.
     const uint64_t words = uint64_t(rows) * uint64_t(W) * uint64_t(spp) * 4u;
-    uint64_t target = std::min<uint64_t>(512, std::max<uint64_t>(1, words >> 16));
+    uint64_t target = std::min<uint64_t>(256, std::max<uint64_t>(1, words >> 16));
     // small frames are bound by the latency of one wave walking its stream: allow up to 64 shorter streams
     target = std::max<uint64_t>(target, std::min<uint64_t>(64, words >> 13));
     if (const char* e = std::getenv("RT_JITTER_STREAMS")) target = (uint64_t)std::max(1, std::atoi(e));
@@ -334,7 +334,7 @@ int dev_stream_states(rt_ctx* c, uint32_t* states, int n, uint64_t stride) {
 int launch_jitter(rt_ctx* c, uint32_t* d_states, const StreamPlan& pl, double* d_out) {
     int rc = dev_stream_states(c, d_states, pl.n, pl.stride);
     if (rc) return rc;
-    hipLaunchKernelGGL(rtk::mt_jitter_kernel, dim3(pl.n), dim3(64), 0, c->rng_stream, d_states, d_out,
+    hipLaunchKernelGGL(rtk::mt_jitter_kernel, dim3(pl.n), dim3(rtk::JITTER_THREADS), 0, c->rng_stream, d_states, d_out,
                        (unsigned long long)(pl.stride / 2), (unsigned long long)(pl.total_words / 2));
     HIP_TRY(hipGetLastError());
     return RT_OK;
@@ -370,7 +370,7 @@ int fill_slot(rt_ctx* c, int k, uint64_t ahead, int rows, int W, int spp) {
                            c->rng_stream, ot.d_states.p, sl.d_states.p, poly);
         HIP_TRY(hipGetLastError());
         if ((rc = dev_jump(c, sl.d_states.p, sl.d_end.p, pl.total_words))) return rc;
-        hipLaunchKernelGGL(rtk::mt_jitter_kernel, dim3(pl.n), dim3(64), 0, c->rng_stream, sl.d_states.p, sl.buf.p,
+        hipLaunchKernelGGL(rtk::mt_jitter_kernel, dim3(pl.n), dim3(rtk::JITTER_THREADS), 0, c->rng_stream, sl.d_states.p, sl.buf.p,
                            (unsigned long long)(pl.stride / 2), (unsigned long long)(pl.total_words / 2));
         HIP_TRY(hipGetLastError());
     } else {

@@ -998,50 +998,46 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
     return y;
 }
 
-__global__ __launch_bounds__(64) void mt_jitter_kernel(const uint32_t* __restrict__ states, double* __restrict__ out,
-                                                       const unsigned long long doubles_per_stream,
-                                                       const unsigned long long total_doubles) {
+constexpr int JITTER_THREADS = 256;  // one workgroup (4 waves) per stream
+
+// One WORKGROUP per stream: the 624-word state lives in LDS and is regenerated in place in three chunks of
+// <= 227 words (word k needs k, k+1 and k+397 of the old block or k-227 of the new one, so 227 words are
+// independent at a time), reads before writes with a barrier in between; then 312 doubles are tempered,
+// converted exactly like libstdc++'s generate_canonical<double,53> and stored.  A stream is a chain of
+// dependent regenerations, so its speed is latency: four waves per stream roughly halve the time per block
+// against one wave walking 64 words at a time, which halves the number of streams (and jump-aheads) a frame
+// needs to keep the sampler hidden behind the traversal.
+__global__ __launch_bounds__(JITTER_THREADS) void mt_jitter_kernel(const uint32_t* __restrict__ states,
+                                                                   double* __restrict__ out,
+                                                                   const unsigned long long doubles_per_stream,
+                                                                   const unsigned long long total_doubles) {
     __shared__ uint32_t x[624];
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x;
     const unsigned long long stream = blockIdx.x;
-    for (int k = lane; k < 624; k += 64) x[k] = states[stream * 624 + k];
+    for (int k = tid; k < 624; k += JITTER_THREADS) x[k] = states[stream * 624 + k];
     unsigned long long pos = stream * doubles_per_stream;
     unsigned long long end = pos + doubles_per_stream;
     if (end > total_doubles) end = total_doubles;
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
     for (; pos < end; pos += 312) {
-        // Two 64-word chunks per step: element k of the new block reads x[k], x[k+1] and
-        // x[k+397 mod 624]; the newest word any of the 128 elements of a step needs was produced
-        // >= 227-128 = 99 elements earlier, i.e. in a previous step, so the pair is independent
-        // and its six LDS reads are in flight together (this kernel runs one wave per CU and is
-        // bound by LDS latency, not throughput).
 #pragma unroll
-        for (int c = 0; c < 10; c += 2) {
-            const int k0 = c * 64 + lane, k1 = k0 + 64;
-            uint32_t n0 = 0, n1 = 0;
-            {
-                const uint32_t xa = x[k0];
-                const uint32_t xb = x[k0 + 1];  // k0 + 1 <= 576
-                const uint32_t xm = x[(k0 + 397 >= 624) ? k0 + 397 - 624 : k0 + 397];
+        for (int c0 = 0; c0 < 624; c0 += 227) {
+            const int k = c0 + tid;
+            const bool on = tid < 227 && k < 624;
+            uint32_t nw = 0;
+            if (on) {
+                const uint32_t xa = x[k];
+                const uint32_t xb = x[(k + 1 == 624) ? 0 : k + 1];  // k = 623 reads the NEW x[0] (written by chunk 0)
+                const uint32_t xm = x[(k + 397 >= 624) ? k + 397 - 624 : k + 397];
                 const uint32_t y = (xa & 0x80000000u) | (xb & 0x7fffffffu);
-                n0 = xm ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+                nw = xm ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
             }
-            if (k1 < 624) {
-                const uint32_t xa = x[k1];
-                const uint32_t xb = x[(k1 + 1 == 624) ? 0 : k1 + 1];  // k1 = 623 reads the NEW x[0] (step 0)
-                const uint32_t xm = x[(k1 + 397 >= 624) ? k1 + 397 - 624 : k1 + 397];
-                const uint32_t y = (xa & 0x80000000u) | (xb & 0x7fffffffu);
-                n1 = xm ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-            }
-            // single wave, LDS executes a wave's operations in order: only the COMPILER must be kept
-            // from moving the step's writes above its reads (other lanes' elements)
-            __builtin_amdgcn_wave_barrier();
-            x[k0] = n0;
-            if (k1 < 624) x[k1] = n1;
-            __builtin_amdgcn_wave_barrier();
+            __syncthreads();
+            if (on) x[k] = nw;
+            __syncthreads();
         }
 #pragma unroll
-        for (int q = lane; q < 312; q += 64) {
+        for (int q = tid; q < 312; q += JITTER_THREADS) {
             if (pos + q < end) {
                 const double wa = (double)mt_temper(x[2 * q]);
                 const double wb = (double)mt_temper(x[2 * q + 1]);
@@ -1051,10 +1047,9 @@ __global__ __launch_bounds__(64) void mt_jitter_kernel(const uint32_t* __restric
                 __builtin_nontemporal_store(ret - 0.5, out + pos + q);  // written once, read once by the next frame
             }
         }
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
     }
 }
-
 
 // ---------------------------------------------------------------------------------------
 // MT19937 jump-ahead on the GPU:  dst = g(A) src  for a polynomial g over GF(2) (312 x 64 bit,
