@@ -59,3 +59,24 @@ def test_write_ppm_roundtrip(tmp_path):
     assert data[len(b"P6\n7 5\n255\n"):] == rgb.tobytes()
     with pytest.raises(ra.RtError):
         ra.write_ppm(tmp_path / "no_such_dir" / "x.ppm", rgb)
+
+
+def test_header_is_plain_c99_and_links_against_the_library(tmp_path):
+    """The boundary is a C ABI: include/rtgpu.h must compile as strict C99 (no C++, no torch types) and a C
+    program using it must link against librtgpu.so and run its host-only entry points."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "use_abi.c"
+    src.write_text(
+        '#include <stdio.h>\n#include "rtgpu.h"\n'
+        "int main(void) {\n"
+        "  int r0 = -1, r1 = -1; uint64_t pos = 0;\n"
+        "  if (rt_shard_rows(4096, 4096, 64, 3, 8, 0, &r0, &r1, &pos) != 0) return 1;\n"
+        '  printf("%s %d %d %llu\\n", rt_version(), r0, r1, (unsigned long long)pos);\n'
+        "  return (r0 == 1536 && r1 == 2048) ? 0 : 2;\n}\n")
+    exe = tmp_path / "use_abi"
+    libdir = os.path.join(root, "raytracer_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(root, "include"),
+                           str(src), "-o", str(exe), "-L", libdir, "-lrtgpu", "-Wl,-rpath," + libdir])
+    out = subprocess.check_output([str(exe)]).decode()
+    assert out.startswith("rtgpu") and " 1536 2048 " in out
