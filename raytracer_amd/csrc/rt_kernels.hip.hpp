@@ -510,7 +510,11 @@ __device__ __forceinline__ unsigned long long slab_rel(const SBox& b, const doub
         const double nz = sz ? b.mxz : b.mnz, fz = sz ? b.mnz : b.mxz;
         const double tmin = __builtin_fmax(__builtin_fmax(nx * ix, ny * iy), nz * iz);
         const double tmax = __builtin_fmin(__builtin_fmin(fx * ix, fy * iy), fz * iz);
-        return __builtin_amdgcn_ballot_w64(tmin <= tmax) & __builtin_amdgcn_ballot_w64(tmax > 0.0);
+        // `tmin <= tmax && tmax > 0` as ONE comparison: tmax > 0 <=> tmax >= the smallest positive double
+        // (fp64 denormals are not flushed on gfx950), so with m = max(tmin, 2^-1074):  m <= tmax  is false when
+        // tmax <= 0 (m > 0), equals tmax > 0 when tmin <= 0, and equals tmin <= tmax (which implies tmax > 0)
+        // when tmin > 0.  Same VALU count, one scalar AND less per box.
+        return __builtin_amdgcn_ballot_w64(__builtin_fmax(tmin, 0x1p-1074) <= tmax);
     }
     const double t0 = b.mnx * ix, t1 = b.mxx * ix;
     const double t2 = b.mny * iy, t3 = b.mxy * iy;

@@ -175,7 +175,8 @@ __device__ __forceinline__ unsigned long long slab32(const float b0, const float
         tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(a.x, c.y), __builtin_fmaxf(a.y, e.x)),
                                __builtin_fmaxf(c.x, e.y));
     }
-    return __builtin_amdgcn_ballot_w64(tmin <= tmax) & __builtin_amdgcn_ballot_w64(tmax > 0.0f);
+    // one comparison (see rtk::slab_rel): boxes whose far distance is below FLT_MIN count as missed here
+    return __builtin_amdgcn_ballot_w64(__builtin_fmaxf(tmin, 0x1p-126f) <= tmax);
 }
 
 __device__ __forceinline__ float u2f(const uint32_t u) { return __builtin_bit_cast(float, u); }
