@@ -517,3 +517,26 @@ def test_long_sequence_through_the_pipelined_driver(ctx, tmp_path):
         for ci, cam in enumerate(cams):
             want = osc.render(*cam, H, W, spp, rng=g, want_hits=False)
             assert (out / f"rtimage_{t}_cam{ci}.ppm").read_bytes() == hdr + want["rgb"].tobytes(), (t, ci)
+
+
+def test_denormal_far_distance_still_counts_as_in_front(ctx):
+    """intersect_AABB accepts a box iff tmin <= tmax && tmax > 0 (rtrayintersection.cpp:143).  The packet
+    kernel folds both into max(tmin, 2^-1074) <= tmax, which is only the same thing if fp64 denormals are
+    neither flushed nor treated as zero: a sheet 1e-320 in front of the camera (tmax denormal) must be hit,
+    the same sheet 1e-320 behind it (tmax < 0) must not, exactly as the oracle says."""
+    for z, expect_hit in ((-1e-320, True), (1e-320, False), (-0.0, False)):
+        tri = np.array([[[[-1.0, -1.0, z], [1.0, -1.0, z], [0.0, 1.0, z]]]])
+        col = np.full((1, 1, 3), 0.25)
+        host = ra.HostScene([tri], [col])
+        ctx.upload(host)
+        cam = np.zeros(3)
+        p00 = np.array([0.25, 0.125, -1.0])  # every direction component non-zero: the FAST slab path
+        sp = np.array([[1e-3, 0.0, 0.0], [0.0, -1e-3, 0.0]])
+        jit = np.zeros((1, 2))
+        ctx.render(cam, p00, sp, 1, 1, 1, jitter=jit, hit_ids=True, hit_t=True)
+        got = ctx.download()
+        want = orc.Scene([tri], [col]).render(cam, p00, sp, 1, 1, 1, jitter=jit)
+        assert (want["hit_elem"][0] >= 0) == expect_hit, z
+        assert (got["hit_prim"][0] >= 0) == expect_hit, z
+        assert np.array_equal(bits(got["hit_t"]), bits(want["hit_t"]))
+        assert np.array_equal(bits(got["intensity"]), bits(want["intensity"]))
