@@ -705,6 +705,24 @@ struct PacketArgs {
     int32_t fast_ok;  // host: >= 1: every |node coordinate - camera| < 1e100; 2: and every box has min <= max
 };
 
+// blockIdx -> tile.  `tile` already gives XCD x (blocks b == x mod 8) a contiguous run of tiles.  When the
+// image divides evenly (tiles_x a multiple of 16, tiles_y of 128) the run is walked in 16x16 blocks of tiles
+// instead of whole tile rows: the ~256 workgroups in flight on an XCD then cover a compact 128x128-pixel
+// square and share more of the tree in the scalar cache and L2 (3 % on the 4096^2 bench frame).
+__device__ __forceinline__ void tile_coords(const int tile, const int n_tiles, const int tiles_x, int& tix, int& tiy) {
+    tix = tile % tiles_x;
+    tiy = tile / tiles_x;
+    const int per = n_tiles >> 3;
+    const int tiles_y = n_tiles / tiles_x;
+    if ((tiles_x & 15) == 0 && (tiles_y & 127) == 0 && (int)blockIdx.x < (per << 3)) {
+        const int xcd = (int)blockIdx.x & 7, local = (int)blockIdx.x >> 3;
+        const int bpr = tiles_x >> 4;  // blocks per row of tiles
+        const int blk = local >> 8, in = local & 255;
+        tix = ((blk % bpr) << 4) + (in & 15);
+        tiy = xcd * (tiles_y >> 3) + ((blk / bpr) << 4) + (in >> 4);
+    }
+}
+
 constexpr int PACKET_STACK = 128;  // entries of the per-wave LDS stack ({descriptor, lane mask}, 16 B each)
 
 // One workgroup = one square pixel tile, one wave = one quarter of the tile's pixels (a compact
@@ -732,8 +750,10 @@ __global__ __launch_bounds__(NT, 8) void render_packet_kernel(const PacketArgs a
     const int ts = 1 << a.tile_log2;
     const int npix_w = (ts * ts) >> 2;  // pixels per wave: 16 (8x8 tile) or 64 (16x16 tile)
     const int m0 = wv * npix_w;         // first Morton index of this wave's quadrant
-    const int tx0 = (tile % a.tiles_x) << a.tile_log2;
-    const int ty0 = (tile / a.tiles_x) << a.tile_log2;
+    int tix, tiy;
+    tile_coords(tile, a.n_tiles, a.tiles_x, tix, tiy);
+    const int tx0 = tix << a.tile_log2;
+    const int ty0 = tiy << a.tile_log2;
     const int spp = a.spp;
     const int n_rays = npix_w * spp;
     uint4* wstk = s_wstk[wv];

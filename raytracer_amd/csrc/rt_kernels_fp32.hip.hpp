@@ -312,8 +312,10 @@ __global__ __launch_bounds__(NT, 8) void render_packet32_kernel(const Packet32Ar
     const int ts = 1 << a.tile_log2;
     const int npix_w = (ts * ts) >> 2;
     const int m0 = wv * npix_w;
-    const int tx0 = (tile % a.tiles_x) << a.tile_log2;
-    const int ty0 = (tile / a.tiles_x) << a.tile_log2;
+    int tix, tiy;
+    rtk::tile_coords(tile, a.n_tiles, a.tiles_x, tix, tiy);
+    const int tx0 = tix << a.tile_log2;
+    const int ty0 = tiy << a.tile_log2;
     const int spp = a.spp;
     const int n_rays = npix_w * spp;
     uint4* wstk = s_wstk[wv];
