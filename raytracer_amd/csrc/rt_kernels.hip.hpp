@@ -625,10 +625,29 @@ __device__ __forceinline__ void trace_packet(const PacketScene& sc, const unsign
                     const double py = dz * e2x - dx * e2z;
                     const double pz = dx * e2y - dy * e2x;
                     const double det = (e0x * px + e0y * py) + e0z * pz;
-                    if (in && det > 1e-6) {
+                    bool need = in && det > 1e-6;
+                    double unum = 0.0, vnum = 0.0;
+                    if (need) {
+                        unum = (tvx * px + tvy * py) + tvz * pz;
+                        vnum = (dx * qx + dy * qy) + dz * qz;
+                        // Sure rejects, decided on the numerators so that a triangle none of the wave's rays can
+                        // hit costs no division: with 1e-6 < det < 2^700 (FAST: every |coordinate - camera| <
+                        // 1e100 and |direction| <= 1 bound det by 2.4e201) the rounded 1/det is a normal number
+                        // >= 2^-700 with relative error 2^-53, so
+                        //   num < -2^-300        =>  num * inv is a normal negative number: `>= 0` fails;
+                        //   unum + vnum > det * (1 + 2^-30)  =>  had both u in [0,1] and v >= 0 held, u + v would
+                        //                            exceed 1 by 2^-31, far beyond the four roundings involved.
+                        // NaNs compare false and take the full path.  Lanes that are not sure rejects compute
+                        // exactly what they did before, so results are unchanged.
+                        if (FAST) {
+                            const double lo = __builtin_fmin(unum, vnum);
+                            need = !(lo < -0x1p-300 || (unum + vnum) > det * (1.0 + 0x1p-30));
+                        }
+                    }
+                    if (need) {
                         const double inv = 1.0 / det;
-                        const double u = ((tvx * px + tvy * py) + tvz * pz) * inv;
-                        const double v = ((dx * qx + dy * qy) + dz * qz) * inv;
+                        const double u = unum * inv;
+                        const double v = vnum * inv;
                         const double t = tnum * inv;
                         const bool ok = (u >= 0.0) && (u <= 1.0) && (v >= 0.0) && ((u + v) <= 1.0) && (t >= 0.0) &&
                                         (t <= __builtin_inf());
@@ -723,6 +742,37 @@ __device__ __forceinline__ void tile_coords(const int tile, const int n_tiles, c
     }
 }
 
+// ---- the compiler's fp64 division, for operands that need no scaling (see render_packet_kernel) ----
+__device__ __forceinline__ uint32_t hi_abs(const double x) {
+    return (uint32_t)(__builtin_bit_cast(unsigned long long, x) >> 32) & 0x7fffffffu;
+}
+__device__ __forceinline__ double refined_rcp(const double d) {  // v_rcp_f64 + two Newton steps
+    double r = __builtin_amdgcn_rcp(d);
+    r = __builtin_fma(r, __builtin_fma(-d, r, 1.0), r);
+    r = __builtin_fma(r, __builtin_fma(-d, r, 1.0), r);
+    return r;
+}
+__device__ __forceinline__ double div_by(const double n, const double d, const double r) {  // n / d, r = refined_rcp(d)
+    const double q = n * r;
+    return __builtin_fma(__builtin_fma(-d, q, n), r, q);
+}
+// The compiler's fp64 sqrt for 2^-767 <= x < inf (below that it pre-scales by 2^256; zero and infinity are
+// passed through): v_rsq_f64 and the same Goldschmidt steps, without the scaling and class selects.
+__device__ __forceinline__ double sqrt_noscale(const double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = y * 0.5;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
+    g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
+    return g;
+}
+__device__ __forceinline__ double rcp_exact(const double d) {  // 1.0 / d
+    const double r = refined_rcp(d);
+    return __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+}
+
 constexpr int PACKET_STACK = 128;  // entries of the per-wave LDS stack ({descriptor, lane mask}, 16 B each)
 
 // One workgroup = one square pixel tile, one wave = one quarter of the tile's pixels (a compact
@@ -799,27 +849,56 @@ __global__ __launch_bounds__(NT, 8) void render_packet_kernel(const PacketArgs a
         const size_t sidx = cs.sidx;
         double c0 = 0.0, c1 = 0.0, c2 = 0.0;
         double dx = 0.0, dy = 0.0, dz = -1.0;
+        double ddx = 1.0, ddy = 1.0, ddz = 1.0;
         if (active) {
             cdptr fp = (cdptr)(const void*)a.fp;  // cam[0..2] p00[3..5] sp[6..11]
             const d2 jit = cs.jit;
             // cpp/rtrender.cpp:53-58
             const double s0 = (double)px + jit.x;
             const double s1 = (double)(py + a.row0) + jit.y;
-            const double ddx = ((fp[3] + s0 * fp[6]) + s1 * fp[9]) - fp[0];
-            const double ddy = ((fp[4] + s0 * fp[7]) + s1 * fp[10]) - fp[1];
-            const double ddz = ((fp[5] + s0 * fp[8]) + s1 * fp[11]) - fp[2];
-            const double z = (ddx * ddx + ddy * ddy) + ddz * ddz;
-            dx = ddx;
-            dy = ddy;
-            dz = ddz;
-            if (z > 0.0) {  // Eigen normalized(): v / sqrt(squaredNorm) when squaredNorm > 0
-                const double nz = __builtin_sqrt(z);
-                dx = ddx / nz;
-                dy = ddy / nz;
-                dz = ddz / nz;
-            }
+            ddx = ((fp[3] + s0 * fp[6]) + s1 * fp[9]) - fp[0];
+            ddy = ((fp[4] + s0 * fp[7]) + s1 * fp[10]) - fp[1];
+            ddz = ((fp[5] + s0 * fp[8]) + s1 * fp[11]) - fp[2];
         }
-        const double ix = 1.0 / dx, iy = 1.0 / dy, iz = 1.0 / dz;
+        double ix, iy, iz;
+        // The six divisions of a ray (three by the norm, three reciprocals) are 84 of the batch's issue slots as
+        // the compiler expands them (v_div_scale x2, v_rcp, 4 fma, mul, fma, v_div_fmas, v_div_fixup each).  When
+        // every component of every active lane has a binary exponent within +-300, v_div_scale scales nothing,
+        // v_div_fmas is a plain fma and v_div_fixup passes its operand through, so the expansion reduces to the
+        // instructions below -- the same ones, with the denominator's part (reciprocal + two Newton steps)
+        // shared by the three quotients, and `1.0 * r` not multiplied.  Bit-identical; any other wave takes the
+        // compiler's divisions.
+        const uint32_t ex = hi_abs(ddx), ey = hi_abs(ddy), ez = hi_abs(ddz);
+        const uint32_t emin = min(min(ex, ey), ez), emax = max(max(ex, ey), ez);
+        const bool tame_div = emin >= ((1023u - 300u) << 20) && emax < ((1023u + 300u) << 20);
+        if (__builtin_amdgcn_ballot_w64(!tame_div) == 0ull) {
+            const double z = (ddx * ddx + ddy * ddy) + ddz * ddz;  // > 0: Eigen normalized() divides
+            const double nz = sqrt_noscale(z);  // 2^-599 < z < 2^602
+            const double rn = refined_rcp(nz);
+            const double qx = div_by(ddx, nz, rn), qy = div_by(ddy, nz, rn), qz = div_by(ddz, nz, rn);
+            ix = rcp_exact(qx);
+            iy = rcp_exact(qy);
+            iz = rcp_exact(qz);
+            dx = qx;  // inactive lanes (components 1, 1, 1) are masked out of everything below
+            dy = qy;
+            dz = qz;
+        } else {
+            if (active) {
+                const double z = (ddx * ddx + ddy * ddy) + ddz * ddz;
+                dx = ddx;
+                dy = ddy;
+                dz = ddz;
+                if (z > 0.0) {  // Eigen normalized(): v / sqrt(squaredNorm) when squaredNorm > 0
+                    const double nz = __builtin_sqrt(z);
+                    dx = ddx / nz;
+                    dy = ddy / nz;
+                    dz = ddz / nz;
+                }
+            }
+            ix = 1.0 / dx;
+            iy = 1.0 / dy;
+            iz = 1.0 / dz;
+        }
         Hit h;
         h.t = __builtin_inf();
         h.u = 0.0;
@@ -1014,12 +1093,27 @@ __global__ __launch_bounds__(NT) void trace_kernel(const TraceArgs a) {
 // generate_canonical<double,53>: (a + b*2^32) / 2^64, clamped below 1.  Output value is
 // random_double() - 0.5 (cpp/rtrender.cpp:53).
 // ---------------------------------------------------------------------------------------
+// gfx950's three-input bit operation (truth table in the immediate: a = 0xF0, b = 0xCC, c = 0xAA) folds the
+// mask-and-xor pairs of the generator into one VALU instruction each: the sampler runs beside the traversal
+// kernel, which is bound by VALU issue, so every instruction saved here is given back to it.
+__device__ __forceinline__ uint32_t xor_and(const uint32_t a, const uint32_t b, const uint32_t c) {  // a ^ (b & c)
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0x78);
+}
+__device__ __forceinline__ uint32_t bit_select(const uint32_t a, const uint32_t b, const uint32_t m) {
+    return __builtin_amdgcn_bitop3_b32(a, b, m, 0xE4);  // (a & m) | (b & ~m)
+}
 __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
     y ^= (y >> 11);
-    y ^= (y << 7) & 0x9d2c5680u;
-    y ^= (y << 15) & 0xefc60000u;
+    y = xor_and(y, y << 7, 0x9d2c5680u);
+    y = xor_and(y, y << 15, 0xefc60000u);
     y ^= (y >> 18);
     return y;
+}
+// next raw word from x[k], x[k+1], x[k+397]
+__device__ __forceinline__ uint32_t mt_twist(const uint32_t xa, const uint32_t xb, const uint32_t xm) {
+    const uint32_t y = bit_select(xa, xb, 0x80000000u);
+    const uint32_t odd = (uint32_t)((int32_t)(xb << 31) >> 31);  // all ones when the low bit of xb (= of y) is set
+    return xor_and(xm ^ (y >> 1), odd, 0x9908b0dfu);
 }
 
 constexpr int JITTER_THREADS = 256;  // one workgroup (4 waves) per stream
@@ -1053,8 +1147,7 @@ __global__ __launch_bounds__(JITTER_THREADS) void mt_jitter_kernel(const uint32_
                 const uint32_t xa = x[k];
                 const uint32_t xb = x[(k + 1 == 624) ? 0 : k + 1];  // k = 623 reads the NEW x[0] (written by chunk 0)
                 const uint32_t xm = x[(k + 397 >= 624) ? k + 397 - 624 : k + 397];
-                const uint32_t y = (xa & 0x80000000u) | (xb & 0x7fffffffu);
-                nw = xm ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+                nw = mt_twist(xa, xb, xm);
             }
             __syncthreads();
             if (on) x[k] = nw;
@@ -1066,9 +1159,11 @@ __global__ __launch_bounds__(JITTER_THREADS) void mt_jitter_kernel(const uint32_
                 const double wa = (double)mt_temper(x[2 * q]);
                 const double wb = (double)mt_temper(x[2 * q + 1]);
                 const double sum = wa + wb * 4294967296.0;
-                double ret = sum / 18446744073709551616.0;
-                if (ret >= 1.0) ret = 0x1.fffffffffffffp-1;  // nextafter(1.0, 0.0)
-                __builtin_nontemporal_store(ret - 0.5, out + pos + q);  // written once, read once by the next frame
+                const double ret = sum / 18446744073709551616.0;
+                // `if (ret >= 1.0) ret = nextafter(1.0, 0.0)` then `- 0.5`: ret - 0.5 is exact for ret in [0.5, 1],
+                // so the clamp is a min with 0.5 - 2^-53 after the subtraction (one v_min instead of cmp + 2 selects)
+                const double r = __builtin_fmin(ret - 0.5, 0x1.ffffffffffffep-2);
+                __builtin_nontemporal_store(r, out + pos + q);  // written once, read once by the next frame
             }
         }
         __syncthreads();
@@ -1120,8 +1215,7 @@ __device__ __forceinline__ void mt_jump_block(const uint32_t* __restrict__ src, 
                 const uint32_t xa = x[k];
                 const uint32_t xb = x[(k + 1 == 624) ? 0 : k + 1];
                 const uint32_t xm = x[(k + 397 >= 624) ? k + 397 - 624 : k + 397];
-                const uint32_t y = (xa & 0x80000000u) | (xb & 0x7fffffffu);
-                nw = xm ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+                nw = mt_twist(xa, xb, xm);
             }
             __syncthreads();
             if (on) x[k] = nw;
@@ -1133,8 +1227,7 @@ __device__ __forceinline__ void mt_jump_block(const uint32_t* __restrict__ src, 
         const int n = base + tid;
         if (tid < 227 && n < JUMP_WORDS) {
             const uint32_t xa = x[n - 624], xb = x[n - 623], xm = x[n - 227];
-            const uint32_t y = (xa & 0x80000000u) | (xb & 0x7fffffffu);
-            x[n] = xm ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            x[n] = mt_twist(xa, xb, xm);
         }
         __syncthreads();
     }

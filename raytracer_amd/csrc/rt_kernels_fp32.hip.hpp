@@ -241,16 +241,23 @@ __device__ __forceinline__ void trace_packet32(const Packet32Args& sc, const uns
                         const float tvx = tp[6], tvy = tp[7], tvz = tp[8];
                         const float qx = tp[9], qy = tp[10], qz = tp[11];
                         const float tnum = tp[12];
-                        const float inv = __builtin_amdgcn_rcpf(det);
-                        const float u = ((tvx * px + tvy * py) + tvz * pz) * inv;
-                        const float v = ((dx * qx + dy * qy) + dz * qz) * inv;
-                        const float t = tnum * inv;
-                        const bool ok = (u >= 0.0f) && (u <= 1.0f) && (v >= 0.0f) && ((u + v) <= 1.0f) && (t >= 0.0f);
-                        if (ok && t < h.t) {
-                            h.t = t;
-                            h.u = u;
-                            h.v = v;
-                            h.prim = (int32_t)(first + k);
+                        const float unum = (tvx * px + tvy * py) + tvz * pz;
+                        const float vnum = (dx * qx + dy * qy) + dz * qz;
+                        // sure rejects on the numerators (see rtk::trace_packet): a triangle that none of the
+                        // wave's rays can hit costs no reciprocal and no range checks
+                        if (!(__builtin_fminf(unum, vnum) < -0x1p-60f || (unum + vnum) > det * (1.0f + 0x1p-18f))) {
+                            const float inv = __builtin_amdgcn_rcpf(det);
+                            const float u = unum * inv;
+                            const float v = vnum * inv;
+                            const float t = tnum * inv;
+                            const bool ok =
+                                (u >= 0.0f) && (u <= 1.0f) && (v >= 0.0f) && ((u + v) <= 1.0f) && (t >= 0.0f);
+                            if (ok && t < h.t) {
+                                h.t = t;
+                                h.u = u;
+                                h.v = v;
+                                h.prim = (int32_t)(first + k);
+                            }
                         }
                     }
                 }
