@@ -540,3 +540,38 @@ def test_denormal_far_distance_still_counts_as_in_front(ctx):
         assert (got["hit_prim"][0] >= 0) == expect_hit, z
         assert np.array_equal(bits(got["hit_t"]), bits(want["hit_t"]))
         assert np.array_equal(bits(got["intensity"]), bits(want["intensity"]))
+
+
+@pytest.mark.parametrize("spp", [1, 64])
+def test_rays_grazing_triangle_edges_sure_reject_margin(ctx, spp):
+    """Rays through points on triangle edges and within 2^-50 .. 2^-20 (relative) either side of them: the zone
+    in which the packet kernel's sure-reject test on the numerators (u + v against det * (1 + 2^-30), u and v
+    against -2^-300) must hand the lane over to the exact division path.  spp = 64 makes the 64 lanes of a wave
+    the samples of one pixel, so the lanes that are sure rejects sit next to the ones in the margin."""
+    c, k = meshgen.plate(12, side=8.0, z0=-4.0, amp=0.06)
+    tri = c[0]
+    rng = np.random.default_rng(77)
+    eps = [0.0] + [s * 2.0 ** -e for e in (52, 50, 45, 40, 33, 31, 30, 29, 27, 24, 20) for s in (1.0, -1.0)]
+    pts = []
+    for e in range(0, tri.shape[0], 2 if spp == 1 else 9):
+        G = tri[e].mean(0)
+        for a, b in ((0, 1), (1, 2), (2, 0)):
+            P = tri[e, a] + rng.uniform(0.02, 0.98) * (tri[e, b] - tri[e, a])
+            pts += [P + x * (G - P) for x in eps]
+        pts += [tri[e, v] + x * (G - tri[e, v]) for v in range(3) for x in eps[:7]]  # and the vertices
+    pts = np.array(pts)
+    if spp == 64:
+        pts = pts[: (len(pts) // 64) * 64]
+        W, H = 8, len(pts) // 64 // 8
+        pts = pts[: W * H * 64]
+    else:
+        W = 64
+        H = len(pts) // W
+        pts = pts[: W * H]
+    proj = pts * (-4.0 / pts[:, 2:3])  # where the ray from the origin crosses the pixel plane z = -4
+    pix = np.arange(len(pts)) // spp
+    jit = np.stack([proj[:, 0] + 4.0 - (pix % W), 4.0 - proj[:, 1] - (pix // W)], 1)
+    cam = (np.zeros(3), np.array([-4.0, 4.0, -4.0]), np.array([[1.0, 0, 0], [0, -1.0, 0]]))
+    got, want, _ = check_image(ctx, [c], [k], cam, H, W, spp, jitter=jit)
+    hits = (want["hit_elem"] >= 0).mean()
+    assert 0.3 < hits < 1.0  # both sides of the edges are represented
