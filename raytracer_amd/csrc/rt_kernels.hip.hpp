@@ -721,6 +721,7 @@ struct PacketArgs {
     int32_t* hit_prim;
     double* hit_t;
     unsigned long long* counters;
+    int32_t pair64;   // host: spp == 64, 8x8 tiles and stack_need <= PAIR64_STACK: pixels are summed two at a time
     int32_t fast_ok;  // host: >= 1: every |node coordinate - camera| < 1e100; 2: and every box has min <= max
 };
 
@@ -773,7 +774,9 @@ __device__ __forceinline__ double rcp_exact(const double d) {  // 1.0 / d
     return __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
 }
 
+constexpr int PAIR64_STACK = 32;   // stack entries left to the traversal in pair64 mode (see render_packet_kernel)
 constexpr int PACKET_STACK = 128;  // entries of the per-wave LDS stack ({descriptor, lane mask}, 16 B each)
+static_assert((PACKET_STACK - PAIR64_STACK) * 16 >= 3 * 64 * 8, "the second pixel's colours must fit above the pair64 stack");
 
 // One workgroup = one square pixel tile, one wave = one quarter of the tile's pixels (a compact
 // quadrant in Morton order).  A wave walks its own pixels' samples 64 at a time and owns its part
@@ -963,6 +966,35 @@ __global__ __launch_bounds__(NT, 8) void render_packet_kernel(const PacketArgs a
             if (COUNT) n_hits += (h.prim >= 0);
             if (a.hit_prim) __builtin_nontemporal_store(h.prim, a.hit_prim + sidx);
             if (a.hit_t) __builtin_nontemporal_store(h.t, a.hit_t + sidx);
+        }
+        if (a.pair64) {
+            // spp == 64: a batch is exactly one pixel.  Two pixels' colours are kept (the second in the upper
+            // three quarters of the wave's stack, idle between traversals; the host sets pair64 only when the
+            // tree needs <= 32 stack entries) and six lanes then add 64 values each, in sample order, starting
+            // from 0.0 like the generic path: half the dependent adds per pixel, and no index arithmetic.
+            const int second = (base >> 6) & 1;
+            double* dst = second ? reinterpret_cast<double*>(wstk + PAIR64_STACK) : &wcol[0][0];
+            dst[lane] = c0;
+            dst[64 + lane] = c1;
+            dst[128 + lane] = c2;
+            __builtin_amdgcn_wave_barrier();
+            if (second && lane < 6) {
+                const int which = lane >= 3 ? 1 : 0;
+                const int c = lane - 3 * which;
+                const double* src = (which ? reinterpret_cast<const double*>(wstk + PAIR64_STACK) : &wcol[0][0]) + c * 64;
+                double acc = 0.0;
+#pragma unroll
+                for (int s2 = 0; s2 < 64; s2 += 8) {
+                    double v8[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v8[j] = src[s2 + j];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc += v8[j];
+                }
+                wacc[c][(base >> 6) - 1 + which] = acc;
+            }
+            __builtin_amdgcn_wave_barrier();
+            continue;
         }
         wcol[0][lane] = c0;
         wcol[1][lane] = c1;
