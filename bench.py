@@ -352,7 +352,7 @@ def main():
                 traffic = pmc.get("hbm_bytes_per_launch")
                 # the bound that actually binds: non-fused fp64 VALU issue, 256 CU x 4 SIMD x
                 # 16 lanes x 2.4 GHz = 39.3 T lane-ops/s; instruction count from the committed PMC pass
-                vi = pmc.get("void rtk::render_packet_kernel<false>", {}).get("SQ_INSTS_VALU")
+                vi = pmc.get(pmc.get("dominant_kernel", ""), {}).get("SQ_INSTS_VALU")
                 if vi:
                     valu = {"lane_ops_per_launch": vi * 64, "peak_lane_ops_per_s": 39.3e12,
                             "frac_of_fp64_issue_peak": vi * 64 / (kms * 1e-3) / 39.3e12,

@@ -1028,6 +1028,7 @@ int render_impl(rt_ctx* c, const rt_render_params* p, bool pipelined) {
         a.tile_log2 = tile_log2;
         a.tiles_x = tiles_x;
         a.n_tiles = (int32_t)n_tiles;
+        a.pair64 = (spp == 64 && tile_log2 == 3 && c->stack_need <= rtk::PAIR64_STACK && !std::getenv("RT_NO_PAIR64")) ? 1 : 0;
         a.jitter = d_jitter;
         a.intensity = c->intensity.p;
         a.rgb = c->rgb.p;
@@ -1088,10 +1089,14 @@ int render_impl(rt_ctx* c, const rt_render_params* p, bool pipelined) {
         a.pair64 = (spp == 64 && tile_log2 == 3 && c->stack_need <= rtk::PAIR64_STACK && !std::getenv("RT_NO_PAIR64")) ? 1 : 0;
         a.fast_ok = (c->max_abs_coord + std::fabs(ox) + std::fabs(oy) + std::fabs(oz)) < 1e100 ? 2 : 0;
         HIP_TRY(hipEventRecord(c->ev[0], c->stream));
-        if (count)
-            hipLaunchKernelGGL(rtk::render_packet_kernel<true>, dim3((unsigned)n_tiles), dim3(rtk::NT), 0, c->stream, a);
+        if (count && a.pair64)
+            hipLaunchKernelGGL((rtk::render_packet_kernel<true, true>), dim3((unsigned)n_tiles), dim3(rtk::NT), 0, c->stream, a);
+        else if (count)
+            hipLaunchKernelGGL((rtk::render_packet_kernel<true, false>), dim3((unsigned)n_tiles), dim3(rtk::NT), 0, c->stream, a);
+        else if (a.pair64)
+            hipLaunchKernelGGL((rtk::render_packet_kernel<false, true>), dim3((unsigned)n_tiles), dim3(rtk::NT), 0, c->stream, a);
         else
-            hipLaunchKernelGGL(rtk::render_packet_kernel<false>, dim3((unsigned)n_tiles), dim3(rtk::NT), 0, c->stream, a);
+            hipLaunchKernelGGL((rtk::render_packet_kernel<false, false>), dim3((unsigned)n_tiles), dim3(rtk::NT), 0, c->stream, a);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->ev[1], c->stream));
     } else {

@@ -470,6 +470,19 @@ __device__ __forceinline__ double sgpr_f64(const u32x16& v, const int i) {
     return __builtin_bit_cast(double, ((unsigned long long)v[2 * i + 1] << 32) | (unsigned long long)v[2 * i]);
 }
 
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+// A kernel argument read from the kernarg segment AT THE POINT OF USE (the packet kernels' PacketArgs /
+// Packet32Args are the only argument, so a field sits at its offsetof).  The compiler otherwise loads every
+// argument once and keeps it in SGPRs across the traversal loops, which need 60+ SGPRs themselves: the
+// arguments were spilled to VGPR lanes and each v_readlane / v_writelane is a VALU issue slot per batch.
+template <class T, int OFF>
+__device__ __forceinline__ T* karg_ptr() {
+    unsigned long long v;
+    const auto k = __builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(k), "i"(OFF) : "memory");
+    return reinterpret_cast<T*>(v);
+}
+
 struct SBox {  // wave-uniform (scalar) camera-relative box
     double mnx, mny, mnz, mxx, mxy, mxz;
 };
@@ -786,7 +799,11 @@ static_assert((PACKET_STACK - PAIR64_STACK) * 16 >= 3 * 64 * 8, "the second pixe
 // Sample colours go through the wave's LDS slice and are added per pixel in sample order
 // k = 0..spp-1 by one lane per (pixel, channel): bit-identical to the reference's serial sum
 // (cpp/rtrender.cpp:51-60) whatever the tiling or GPU count.
-template <bool COUNT>
+// P64: the host launches this instantiation when spp == 64, tiles are 8x8 and the tree needs <= PAIR64_STACK
+// stack entries (PacketArgs::pair64).  A batch is then exactly one pixel: the pixel's coordinates, its bounds
+// test and the base of its sample index are wave-uniform (scalar unit), divisions by spp disappear, and the
+// per-pixel sums are done two pixels at a time.
+template <bool COUNT, bool P64>
 __global__ __launch_bounds__(NT, 8) void render_packet_kernel(const PacketArgs a) {
     __shared__ uint4 s_wstk[NT / 64][PACKET_STACK];
     __shared__ double s_col[NT / 64][3][64];
@@ -794,7 +811,7 @@ __global__ __launch_bounds__(NT, 8) void render_packet_kernel(const PacketArgs a
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wv = tid >> 6;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform, and the compiler is told so
     int tile = blockIdx.x;
     {
         const int nb = a.n_tiles, per = nb >> 3, main = per << 3;
@@ -807,7 +824,7 @@ __global__ __launch_bounds__(NT, 8) void render_packet_kernel(const PacketArgs a
     tile_coords(tile, a.n_tiles, a.tiles_x, tix, tiy);
     const int tx0 = tix << a.tile_log2;
     const int ty0 = tiy << a.tile_log2;
-    const int spp = a.spp;
+    const int spp = P64 ? 64 : a.spp;
     const int n_rays = npix_w * spp;
     uint4* wstk = s_wstk[wv];
     double(*wcol)[64] = s_col[wv];
@@ -831,8 +848,8 @@ __global__ __launch_bounds__(NT, 8) void render_packet_kernel(const PacketArgs a
     auto fetch = [&](const int base) {
         Slot q;
         const int rr = base + lane;
-        const int ml = rr / spp;
-        const int k = rr - ml * spp;
+        const int ml = P64 ? (base >> 6) : rr / spp;  // P64: wave-uniform
+        const int k = P64 ? lane : rr - ml * spp;
         const int m = m0 + ml;
         q.px = tx0 + (int)compact1by1((uint32_t)m);
         q.py = ty0 + (int)compact1by1((uint32_t)m >> 1);
@@ -840,7 +857,8 @@ __global__ __launch_bounds__(NT, 8) void render_packet_kernel(const PacketArgs a
         q.sidx = q.active ? ((size_t)q.py * a.W + q.px) * (size_t)spp + k : 0;
         q.jit = d2{0.0, 0.0};
         // streamed once: non-temporal, so the 16 B/sample stream does not displace tree nodes in L2
-        if (q.active) q.jit = __builtin_nontemporal_load(reinterpret_cast<const d2*>(a.jitter) + q.sidx);
+        if (q.active)
+            q.jit = __builtin_nontemporal_load(karg_ptr<const d2, offsetof(PacketArgs, jitter)>() + q.sidx);
         return q;
     };
     Slot nxt = fetch(0);
@@ -853,15 +871,32 @@ __global__ __launch_bounds__(NT, 8) void render_packet_kernel(const PacketArgs a
         double c0 = 0.0, c1 = 0.0, c2 = 0.0;
         double dx = 0.0, dy = 0.0, dz = -1.0;
         double ddx = 1.0, ddy = 1.0, ddz = 1.0;
-        if (active) {
-            cdptr fp = (cdptr)(const void*)a.fp;  // cam[0..2] p00[3..5] sp[6..11]
+        {
+            // the camera block (12 doubles) is fetched here, every batch, with scalar loads pinned to this spot:
+            // hoisted out of the loop it would hold 24 SGPRs across the traversal
+            u32x16 fa;  // cam[0..2] p00[0..2] sp[0..1]
+            u32x8 fb;   // sp[2..5]
+            const FrameParams* fpp = karg_ptr<const FrameParams, offsetof(PacketArgs, fp)>();
+            asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx8 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&s"(fa), "=&s"(fb)
+                         : "s"(fpp)
+                         : "memory");
             const d2 jit = cs.jit;
             // cpp/rtrender.cpp:53-58
             const double s0 = (double)px + jit.x;
             const double s1 = (double)(py + a.row0) + jit.y;
-            ddx = ((fp[3] + s0 * fp[6]) + s1 * fp[9]) - fp[0];
-            ddy = ((fp[4] + s0 * fp[7]) + s1 * fp[10]) - fp[1];
-            ddz = ((fp[5] + s0 * fp[8]) + s1 * fp[11]) - fp[2];
+            const double sp2 = __builtin_bit_cast(double, ((unsigned long long)fb[1] << 32) | fb[0]);
+            const double sp3 = __builtin_bit_cast(double, ((unsigned long long)fb[3] << 32) | fb[2]);
+            const double sp4 = __builtin_bit_cast(double, ((unsigned long long)fb[5] << 32) | fb[4]);
+            const double sp5 = __builtin_bit_cast(double, ((unsigned long long)fb[7] << 32) | fb[6]);
+            const double tx = ((sgpr_f64(fa, 3) + s0 * sgpr_f64(fa, 6)) + s1 * sp3) - sgpr_f64(fa, 0);
+            const double ty = ((sgpr_f64(fa, 4) + s0 * sgpr_f64(fa, 7)) + s1 * sp4) - sgpr_f64(fa, 1);
+            const double tz = ((sgpr_f64(fa, 5) + s0 * sp2) + s1 * sp5) - sgpr_f64(fa, 2);
+            if (active) {
+                ddx = tx;
+                ddy = ty;
+                ddz = tz;
+            }
         }
         double ix, iy, iz;
         // The six divisions of a ray (three by the norm, three reciprocals) are 84 of the batch's issue slots as
@@ -950,7 +985,7 @@ __global__ __launch_bounds__(NT, 8) void render_packet_kernel(const PacketArgs a
         if (active) {
             // return_ray_color, cpp/rtrender.cpp:21-32
             if (h.t != __builtin_inf()) {
-                const double* fc = a.sc.colors + (size_t)h.prim * 3;
+                const double* fc = karg_ptr<const double, offsetof(PacketArgs, sc) + offsetof(PacketScene, colors)>() + (size_t)h.prim * 3;
                 const double w = (1.0 - h.u) - h.v;
                 const double f0 = fc[0], f1 = fc[1], f2 = fc[2];
                 c0 = (h.u * f0 + h.v * f0) + w * f0;
@@ -964,10 +999,12 @@ __global__ __launch_bounds__(NT, 8) void render_packet_kernel(const PacketArgs a
                 c2 = ia + al * 1.0;
             }
             if (COUNT) n_hits += (h.prim >= 0);
-            if (a.hit_prim) __builtin_nontemporal_store(h.prim, a.hit_prim + sidx);
-            if (a.hit_t) __builtin_nontemporal_store(h.t, a.hit_t + sidx);
+            int32_t* const hit_prim = karg_ptr<int32_t, offsetof(PacketArgs, hit_prim)>();
+            double* const hit_t = karg_ptr<double, offsetof(PacketArgs, hit_t)>();
+            if (hit_prim) __builtin_nontemporal_store(h.prim, hit_prim + sidx);
+            if (hit_t) __builtin_nontemporal_store(h.t, hit_t + sidx);
         }
-        if (a.pair64) {
+        if (P64) {
             // spp == 64: a batch is exactly one pixel.  Two pixels' colours are kept (the second in the upper
             // three quarters of the wave's stack, idle between traversals; the host sets pair64 only when the
             // tree needs <= 32 stack entries) and six lanes then add 64 values each, in sample order, starting
@@ -1039,11 +1076,12 @@ __global__ __launch_bounds__(NT, 8) void render_packet_kernel(const PacketArgs a
             const double inten = gray / (double)spp;
             const int gb = (int)(inten * 255.99);
             const size_t pidx = (size_t)py * a.W + px;
-            a.intensity[pidx] = inten;
+            karg_ptr<double, offsetof(PacketArgs, intensity)>()[pidx] = inten;
             const uint8_t g8 = (uint8_t)gb;
-            a.rgb[pidx * 3] = g8;
-            a.rgb[pidx * 3 + 1] = g8;
-            a.rgb[pidx * 3 + 2] = g8;
+            uint8_t* const rgb = karg_ptr<uint8_t, offsetof(PacketArgs, rgb)>();
+            rgb[pidx * 3] = g8;
+            rgb[pidx * 3 + 1] = g8;
+            rgb[pidx * 3 + 2] = g8;
         }
     }
 

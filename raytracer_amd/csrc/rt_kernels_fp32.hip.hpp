@@ -138,6 +138,7 @@ struct Packet32Args {
     int32_t row0, rows;
     int32_t tile_log2;
     int32_t tiles_x, n_tiles;
+    int32_t pair64;  // spp == 64 and stack_need <= rtk::PAIR64_STACK
     const double* jitter;
     double* intensity;
     uint8_t* rgb;
@@ -446,6 +447,31 @@ __global__ __launch_bounds__(NT, 8) void render_packet32_kernel(const Packet32Ar
             if (COUNT) n_hits += (h.prim >= 0);
             if (a.hit_prim) __builtin_nontemporal_store(h.prim, a.hit_prim + sidx);
             if (a.hit_t) __builtin_nontemporal_store((double)h.t, a.hit_t + sidx);
+        }
+        if (a.pair64) {  // spp == 64: two pixels summed at a time, see rtk::render_packet_kernel
+            const int second = (base >> 6) & 1;
+            float* dst = second ? reinterpret_cast<float*>(wstk + rtk::PAIR64_STACK) : &wcol[0][0];
+            dst[lane] = c0;
+            dst[64 + lane] = c1;
+            dst[128 + lane] = c2;
+            __builtin_amdgcn_wave_barrier();
+            if (second && lane < 6) {
+                const int which = lane >= 3 ? 1 : 0;
+                const int c = lane - 3 * which;
+                const float* src = (which ? reinterpret_cast<const float*>(wstk + rtk::PAIR64_STACK) : &wcol[0][0]) + c * 64;
+                float acc = 0.0f;
+#pragma unroll
+                for (int s2 = 0; s2 < 64; s2 += 8) {
+                    float v8[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v8[j] = src[s2 + j];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc += v8[j];
+                }
+                wacc[c][(base >> 6) - 1 + which] = acc;
+            }
+            __builtin_amdgcn_wave_barrier();
+            continue;
         }
         wcol[0][lane] = c0;
         wcol[1][lane] = c1;
