@@ -1228,11 +1228,12 @@ __global__ __launch_bounds__(JITTER_THREADS) void mt_jitter_kernel(const uint32_
             if (pos + q < end) {
                 const double wa = (double)mt_temper(x[2 * q]);
                 const double wb = (double)mt_temper(x[2 * q + 1]);
-                const double sum = wa + wb * 4294967296.0;
-                const double ret = sum / 18446744073709551616.0;
+                // wb * 2^32 and sum * 2^-64 are exact (powers of two, no under/overflow), so each explicit fma below
+                // rounds once, exactly where `wa + wb * 2^32` and `sum / 2^64 - 0.5` round: same bits, two VALU less
+                const double sum = __builtin_fma(wb, 4294967296.0, wa);
                 // `if (ret >= 1.0) ret = nextafter(1.0, 0.0)` then `- 0.5`: ret - 0.5 is exact for ret in [0.5, 1],
                 // so the clamp is a min with 0.5 - 2^-53 after the subtraction (one v_min instead of cmp + 2 selects)
-                const double r = __builtin_fmin(ret - 0.5, 0x1.ffffffffffffep-2);
+                const double r = __builtin_fmin(__builtin_fma(sum, 0x1p-64, -0.5), 0x1.ffffffffffffep-2);
                 __builtin_nontemporal_store(r, out + pos + q);  // written once, read once by the next frame
             }
         }
