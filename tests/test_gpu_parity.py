@@ -575,3 +575,32 @@ def test_rays_grazing_triangle_edges_sure_reject_margin(ctx, spp):
     got, want, _ = check_image(ctx, [c], [k], cam, H, W, spp, jitter=jit)
     hits = (want["hit_elem"] >= 0).mean()
     assert 0.3 < hits < 1.0  # both sides of the edges are represented
+
+
+def test_64_spp_instantiation_equals_generic_and_is_skipped_for_deep_trees(ctx, monkeypatch):
+    """spp = 64 runs render_packet_kernel<.., P64 = true> (pixel pairs summed together, colours of the second
+    pixel parked in the upper part of the wave's stack); RT_NO_PAIR64 forces the generic instantiation, and a tree
+    needing more than 32 stack entries must get the generic one by itself.  All three against the oracle."""
+    c, k = meshgen.plate(40, amp=0.1)
+    cam = meshgen.camera_arrays(37, 21)  # odd sizes: partly empty tiles, inactive pixels in a pair
+    a, want, _ = check_image(ctx, [c], [k], cam, 21, 37, 64)
+    monkeypatch.setenv("RT_NO_PAIR64", "1")
+    b, _, _ = check_image(ctx, [c], [k], cam, 21, 37, 64)
+    monkeypatch.delenv("RT_NO_PAIR64")
+    assert np.array_equal(bits(a["intensity"]), bits(b["intensity"]))
+    assert np.array_equal(a["hit_prim"], b["hit_prim"])
+    # deep, left-leaning trees: stack_need == 32 (the deepest the 64-spp instantiation takes: the traversal's
+    # entries end right below the parked colours) and 50 (packet kernel, but the generic instantiation)
+    for n_t, lo, hi in ((65, 32, 32), (100, 33, 128)):
+        tris = []
+        for i in range(n_t):
+            x = 3.0 ** i * 1e-6
+            tris.append([[x, -1.0, -3.0], [x * 1.5, -1.0, -3.0], [x, 1.0, -3.0]])
+        cd = np.array(tris)[None]
+        kd = np.linspace(0.2, 0.8, n_t)[None, :, None].repeat(3, 2)
+        host = ra.HostScene([cd], [kd])
+        assert lo <= host.info.stack_need <= hi, host.info.stack_need
+        # a narrow view just right of x = 0, where the small triangles (the deep end of the tree) are
+        cam = (np.zeros(3), np.array([1e-6, 0.5, -3.0]), np.array([[2e-4, 0, 0], [0, -0.125, 0]]))
+        got, want, _ = check_image(ctx, [cd], [kd], cam, 8, 16, 64)
+        assert (want["hit_elem"] >= 0).mean() > 0.2
