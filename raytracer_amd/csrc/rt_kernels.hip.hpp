@@ -627,12 +627,23 @@ __device__ __forceinline__ void trace_packet(const PacketScene& sc, const unsign
                 if (COUNT) wc.tris += (unsigned long long)cnt * (unsigned)__builtin_popcountll(inm);
                 const bool in = __builtin_amdgcn_inverse_ballot_w64(inm);
                 for (uint32_t k = 0; k < cnt; ++k) {
-                    cdptr tp = (cdptr)(const void*)(sc.tris + (size_t)(first + k));
-                    const double e0x = tp[0], e0y = tp[1], e0z = tp[2];
-                    const double e2x = tp[3], e2y = tp[4], e2z = tp[5];
-                    const double tvx = tp[6], tvy = tp[7], tvz = tp[8];
-                    const double qx = tp[9], qy = tp[10], qz = tp[11];
-                    const double tnum = tp[12];
+                    // the whole 128-byte record in one round trip (both 64-byte lines requested together): staged
+                    // loads (edges, then tv/q, then tnum) put up to three dependent scalar-cache misses on the
+                    // wave's critical path per triangle
+                    u32x16 ta, tb;
+                    {
+                        const CamTri* trec = sc.tris + (size_t)(first + k);
+                        asm volatile(
+                            "s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)"
+                            : "=&s"(ta), "=&s"(tb)
+                            : "s"(trec)
+                            : "memory");
+                    }
+                    const double e0x = sgpr_f64(ta, 0), e0y = sgpr_f64(ta, 1), e0z = sgpr_f64(ta, 2);
+                    const double e2x = sgpr_f64(ta, 3), e2y = sgpr_f64(ta, 4), e2z = sgpr_f64(ta, 5);
+                    const double tvx = sgpr_f64(ta, 6), tvy = sgpr_f64(ta, 7), tvz = sgpr_f64(tb, 0);
+                    const double qx = sgpr_f64(tb, 1), qy = sgpr_f64(tb, 2), qz = sgpr_f64(tb, 3);
+                    const double tnum = sgpr_f64(tb, 4);
                     // rtrayintersection.cpp:79-106, with the ray-independent parts precomputed
                     const double px = dy * e2z - dz * e2y;
                     const double py = dz * e2x - dx * e2z;

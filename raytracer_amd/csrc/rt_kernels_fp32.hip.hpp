@@ -231,17 +231,21 @@ __device__ __forceinline__ void trace_packet32(const Packet32Args& sc, const uns
                 if (COUNT) wc.tris += (unsigned long long)cnt * (unsigned)__builtin_popcountll(inm);
                 const bool in = __builtin_amdgcn_inverse_ballot_w64(inm);
                 for (uint32_t k = 0; k < cnt; ++k) {
-                    cfptr tp = (cfptr)(const void*)(sc.tris + (size_t)(first + k));
-                    const float e0x = tp[0], e0y = tp[1], e0z = tp[2];
-                    const float e2x = tp[3], e2y = tp[4], e2z = tp[5];
+                    rtk::u32x16 tr;  // the whole 64-byte record in one scalar round trip
+                    {
+                        const Tri32* trec = sc.tris + (size_t)(first + k);
+                        asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tr) : "s"(trec) : "memory");
+                    }
+                    const float e0x = u2f(tr[0]), e0y = u2f(tr[1]), e0z = u2f(tr[2]);
+                    const float e2x = u2f(tr[3]), e2y = u2f(tr[4]), e2z = u2f(tr[5]);
                     const float px = dy * e2z - dz * e2y;
                     const float py = dz * e2x - dx * e2z;
                     const float pz = dx * e2y - dy * e2x;
                     const float det = (e0x * px + e0y * py) + e0z * pz;
                     if (in && det > 1e-6f) {
-                        const float tvx = tp[6], tvy = tp[7], tvz = tp[8];
-                        const float qx = tp[9], qy = tp[10], qz = tp[11];
-                        const float tnum = tp[12];
+                        const float tvx = u2f(tr[6]), tvy = u2f(tr[7]), tvz = u2f(tr[8]);
+                        const float qx = u2f(tr[9]), qy = u2f(tr[10]), qz = u2f(tr[11]);
+                        const float tnum = u2f(tr[12]);
                         const float unum = (tvx * px + tvy * py) + tvz * pz;
                         const float vnum = (dx * qx + dy * qy) + dz * qz;
                         // sure rejects on the numerators (see rtk::trace_packet): a triangle that none of the
