@@ -5,12 +5,17 @@
 //                      only on the camera centre, computed once per frame with the reference's operations)
 //   render_packet_kernel   THE hot kernel: ray generation + wave-packet TLAS/BLAS traversal on the scalar
 //                      unit + Moller-Trumbore + shading + in-order sample accumulation + luma/quantise
-//                      (reference: cpp/rtrender.cpp:13-67, cpp/rtrayintersection.cpp:36-228)
+//                      (reference: cpp/rtrender.cpp:13-67, cpp/rtrayintersection.cpp:36-228);
+//                      <COUNT, P64>: with visit counters / the 64-spp instantiation (a batch = one pixel)
 //   render_kernel      the same per lane (LDS or global stack): trees deeper than the packet stack
 //   trace_kernel       the same traversal for caller-supplied rays (rt_trace_rays, test seam)
 //   mt_jump_kernel / mt_jump_tree_kernel / mt_jump_all_kernel   GF(2) jump-ahead of MT19937 states
-//   mt_jitter_kernel   MT19937 words -> random_double()-0.5 values, one wave per jump-ahead
+//   mt_jitter_kernel   MT19937 words -> random_double()-0.5 values, one workgroup per jump-ahead
 //                      stream (reference: cpp/rtmathutils.h:15-19, cpp/rtrender.cpp:53)
+//   philox_jitter_kernel   counter-based fast sampler (RT_SAMPLER_PHILOX; not the reference's stream)
+// Explicit __builtin_fma appears only where the result is provably the one the unfused reference sequence
+// gives: in the hand-issued copies of the compiler's own division / square-root expansions, and where the
+// product is exact (a power-of-two factor).
 //   (the fp32 fast path lives in rt_kernels_fp32.hip.hpp)
 //
 // Numerics contract (parity with the reference's x86-64 -O2 build): IEEE binary64, no FMA
@@ -1168,11 +1173,9 @@ __global__ __launch_bounds__(NT) void trace_kernel(const TraceArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------
-// MT19937 jitter.  One wave per stream; the 624-word state lives in LDS and is regenerated
-// in place in ten 64-lane chunks (a chunk only reads words that earlier chunks, or the
-// previous block, produced), then tempered and converted pairwise exactly like libstdc++'s
-// generate_canonical<double,53>: (a + b*2^32) / 2^64, clamped below 1.  Output value is
-// random_double() - 0.5 (cpp/rtrender.cpp:53).
+// MT19937 jitter.  One workgroup per stream (see mt_jitter_kernel); words are tempered and converted
+// pairwise exactly like libstdc++'s generate_canonical<double,53>: (a + b*2^32) / 2^64, clamped below 1.
+// Output value is random_double() - 0.5 (cpp/rtrender.cpp:53).
 // ---------------------------------------------------------------------------------------
 // gfx950's three-input bit operation (truth table in the immediate: a = 0xF0, b = 0xCC, c = 0xAA) folds the
 // mask-and-xor pairs of the generator into one VALU instruction each: the sampler runs beside the traversal
