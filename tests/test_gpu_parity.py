@@ -233,9 +233,10 @@ def test_deep_tree_uses_global_stack(ctx):
     check_image(ctx, [c], [k], cam, 8, 8, 2)
 
 
-def test_row_bands_equal_full_image(ctx):
+@pytest.mark.parametrize("spp", [3, 64])  # 64: the one-pixel-per-batch instantiation, with row0 != 0
+def test_row_bands_equal_full_image(ctx, spp):
     c, k = meshgen.plate(32)
-    H, W, spp = 40, 24, 3
+    H, W = 40, 24
     cam = meshgen.camera_arrays(W, H)
     host = ra.HostScene([c], [k])
     ctx.upload(host)
