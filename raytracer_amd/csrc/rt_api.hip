@@ -1086,7 +1086,10 @@ int render_impl(rt_ctx* c, const rt_render_params* p, bool pipelined) {
         a.counters = count ? c->counters.p : nullptr;
         // finite coordinates => every node box (>= 1 triangle, rt_scene_build rejects empty meshes) has
         // min <= max, and so has its camera-relative copy (subtraction rounds monotonically): level 2
-        a.pair64 = (spp == 64 && tile_log2 == 3 && c->stack_need <= rtk::PAIR64_STACK && !std::getenv("RT_NO_PAIR64")) ? 1 : 0;
+        a.pair64 = 0;  // 1 + log2(spp / 64) for spp = 64, 128, 256, ...: the one-pixel-per-batch instantiation
+        if (spp >= 64 && (spp & (spp - 1)) == 0 && tile_log2 == 3 && c->stack_need <= rtk::PAIR64_STACK &&
+            !std::getenv("RT_NO_PAIR64"))
+            for (int q = spp >> 6; q; q >>= 1) ++a.pair64;
         a.fast_ok = (c->max_abs_coord + std::fabs(ox) + std::fabs(oy) + std::fabs(oz)) < 1e100 ? 2 : 0;
         HIP_TRY(hipEventRecord(c->ev[0], c->stream));
         if (count && a.pair64)

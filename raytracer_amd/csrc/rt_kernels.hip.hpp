@@ -750,7 +750,7 @@ struct PacketArgs {
     int32_t* hit_prim;
     double* hit_t;
     unsigned long long* counters;
-    int32_t pair64;   // host: spp == 64, 8x8 tiles and stack_need <= PAIR64_STACK: pixels are summed two at a time
+    int32_t pair64;   // host: 1 + log2(spp / 64) when spp = 64 * 2^n, tiles are 8x8 and stack_need <= PAIR64_STACK; else 0
     int32_t fast_ok;  // host: >= 1: every |node coordinate - camera| < 1e100; 2: and every box has min <= max
 };
 
@@ -815,8 +815,8 @@ static_assert((PACKET_STACK - PAIR64_STACK) * 16 >= 3 * 64 * 8, "the second pixe
 // Sample colours go through the wave's LDS slice and are added per pixel in sample order
 // k = 0..spp-1 by one lane per (pixel, channel): bit-identical to the reference's serial sum
 // (cpp/rtrender.cpp:51-60) whatever the tiling or GPU count.
-// P64: the host launches this instantiation when spp == 64, tiles are 8x8 and the tree needs <= PAIR64_STACK
-// stack entries (PacketArgs::pair64).  A batch is then exactly one pixel: the pixel's coordinates, its bounds
+// P64: the host launches this instantiation when spp is 64, 128, 256, ... (a power of two), tiles are 8x8 and the
+// tree needs <= PAIR64_STACK stack entries (PacketArgs::pair64 = 1 + log2(spp / 64)).  A batch then lies in one pixel: the pixel's coordinates, its bounds
 // test and the base of its sample index are wave-uniform (scalar unit), divisions by spp disappear, and the
 // per-pixel sums are done two pixels at a time.
 template <bool COUNT, bool P64>
@@ -840,7 +840,8 @@ __global__ __launch_bounds__(NT, 8) void render_packet_kernel(const PacketArgs a
     tile_coords(tile, a.n_tiles, a.tiles_x, tix, tiy);
     const int tx0 = tix << a.tile_log2;
     const int ty0 = tiy << a.tile_log2;
-    const int spp = P64 ? 64 : a.spp;
+    const int lg64 = P64 ? a.pair64 - 1 : 0;  // P64: spp = 64 << lg64
+    const int spp = P64 ? (64 << lg64) : a.spp;
     const int n_rays = npix_w * spp;
     uint4* wstk = s_wstk[wv];
     double(*wcol)[64] = s_col[wv];
@@ -864,8 +865,8 @@ __global__ __launch_bounds__(NT, 8) void render_packet_kernel(const PacketArgs a
     auto fetch = [&](const int base) {
         Slot q;
         const int rr = base + lane;
-        const int ml = P64 ? (base >> 6) : rr / spp;  // P64: wave-uniform
-        const int k = P64 ? lane : rr - ml * spp;
+        const int ml = P64 ? (base >> (6 + lg64)) : rr / spp;  // P64: wave-uniform
+        const int k = P64 ? (base & (spp - 1)) + lane : rr - ml * spp;
         const int m = m0 + ml;
         q.px = tx0 + (int)compact1by1((uint32_t)m);
         q.py = ty0 + (int)compact1by1((uint32_t)m >> 1);
@@ -1021,30 +1022,37 @@ __global__ __launch_bounds__(NT, 8) void render_packet_kernel(const PacketArgs a
             if (hit_t) __builtin_nontemporal_store(h.t, hit_t + sidx);
         }
         if (P64) {
-            // spp == 64: a batch is exactly one pixel.  Two pixels' colours are kept (the second in the upper
-            // three quarters of the wave's stack, idle between traversals; the host sets pair64 only when the
-            // tree needs <= 32 stack entries) and six lanes then add 64 values each, in sample order, starting
-            // from 0.0 like the generic path: half the dependent adds per pixel, and no index arithmetic.
+            // spp = 64 << lg64: a batch lies within one pixel.  The colours of two batches are kept (the second in
+            // the upper three quarters of the wave's stack, idle between traversals; the host selects this
+            // instantiation only when the tree needs <= 32 stack entries).  spp == 64: the two batches are two
+            // pixels and six lanes add 64 values each, in sample order, starting from 0.0 like the generic path:
+            // half the dependent adds per pixel.  spp >= 128: both belong to the same pixel and three lanes
+            // continue that pixel's running sums with 128 values.  No index arithmetic either way.
             const int second = (base >> 6) & 1;
-            double* dst = second ? reinterpret_cast<double*>(wstk + PAIR64_STACK) : &wcol[0][0];
+            double* const parked = reinterpret_cast<double*>(wstk + PAIR64_STACK);
+            double* dst = second ? parked : &wcol[0][0];
             dst[lane] = c0;
             dst[64 + lane] = c1;
             dst[128 + lane] = c2;
             __builtin_amdgcn_wave_barrier();
-            if (second && lane < 6) {
+            if (second && lane < (lg64 == 0 ? 6 : 3)) {
                 const int which = lane >= 3 ? 1 : 0;
                 const int c = lane - 3 * which;
-                const double* src = (which ? reinterpret_cast<const double*>(wstk + PAIR64_STACK) : &wcol[0][0]) + c * 64;
-                double acc = 0.0;
+                const int pm = lg64 == 0 ? (base >> 6) - 1 + which : (base >> (6 + lg64));
+                double acc = lg64 == 0 ? 0.0 : wacc[c][pm];
+                const double* src = (which ? parked : &wcol[0][0]) + c * 64;
+                for (int half = 0; half < (lg64 == 0 ? 1 : 2); ++half) {
 #pragma unroll
-                for (int s2 = 0; s2 < 64; s2 += 8) {
-                    double v8[8];
+                    for (int s2 = 0; s2 < 64; s2 += 8) {
+                        double v8[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v8[j] = src[s2 + j];
+                        for (int j = 0; j < 8; ++j) v8[j] = src[s2 + j];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) acc += v8[j];
+                        for (int j = 0; j < 8; ++j) acc += v8[j];
+                    }
+                    src = parked + c * 64;
                 }
-                wacc[c][(base >> 6) - 1 + which] = acc;
+                wacc[c][pm] = acc;
             }
             __builtin_amdgcn_wave_barrier();
             continue;

@@ -124,7 +124,7 @@ def test_trace_axis_aligned_rays_nan_slab_order(ctx):
     assert (want["elem"] >= 0).sum() > 50
 
 
-@pytest.mark.parametrize("spp", [1, 3, 4, 50, 64])
+@pytest.mark.parametrize("spp", [1, 3, 4, 50, 64, 128, 192, 256])
 def test_render_plate_matches_oracle(ctx, spp):
     c, k = meshgen.plate(48)
     cam = meshgen.camera_arrays(40, 24)
