@@ -980,7 +980,17 @@ int render_impl(rt_ctx* c, const rt_render_params* p, bool pipelined) {
     const double* d_jitter = c->slot[use].buf.p;
 
     // ---- traversal ----
-    const int tile_log2 = (spp >= 4) ? 3 : 4;  // >= 256 rays per 8x8 tile from 4 spp on
+    // the packet kernels address nodes with a 32-bit scalar byte offset: node array < 4 GB (6.7e7 nodes)
+    const bool packet = c->stack_need <= rtk::PACKET_STACK && !force_per_lane() && c->n_nodes < (size_t(1) << 26);
+    int tile_log2 = (spp >= 4) ? 3 : 4;  // >= 256 rays per 8x8 tile from 4 spp on
+    // Small images (the reference's own 400x225 frames): one workgroup per 8x8 tile leaves most of the 2048
+    // workgroup slots of the chip empty.  The packet kernels take any tile size, so halve the tile while there
+    // are fewer than 8192 tiles and a wave (a quarter of the tile) still has >= 128 rays to walk.
+    static const bool small_tiles = std::getenv("RT_NO_SMALL_TILES") == nullptr;
+    if (small_tiles && (packet || (p->flags & RT_FLAG_FP32)))
+        while (tile_log2 > 1 && int64_t((W + (1 << tile_log2) - 1) >> tile_log2) * ((rows + (1 << tile_log2) - 1) >> tile_log2) < 8192 &&
+               (int64_t(1) << (2 * (tile_log2 - 1) - 2)) * spp >= 128)
+            --tile_log2;
     const int ts = 1 << tile_log2;
     const int tiles_x = (W + ts - 1) / ts;
     const int tiles_y = (rows + ts - 1) / ts;
@@ -988,8 +998,6 @@ int render_impl(rt_ctx* c, const rt_render_params* p, bool pipelined) {
     if (n_tiles > 0x7fffffff) return fail(RT_E_LIMIT, "rt_render: too many tiles");
     const bool count = (p->flags & RT_FLAG_COUNTERS) != 0;
     if (count) HIP_TRY(hipMemsetAsync(c->counters.p, 0, 4 * sizeof(unsigned long long), c->stream));
-    // the packet kernels address nodes with a 32-bit scalar byte offset: node array < 4 GB (6.7e7 nodes)
-    const bool packet = c->stack_need <= rtk::PACKET_STACK && !force_per_lane() && c->n_nodes < (size_t(1) << 26);
     if (p->flags & RT_FLAG_FP32) {
         // fp32 FAST PATH (not the parity path): same walk in binary32, see rt_kernels_fp32.hip.hpp
         if (c->stack_need > rtk::PACKET_STACK || c->n_nodes >= (size_t(1) << 26))
@@ -1028,7 +1036,7 @@ int render_impl(rt_ctx* c, const rt_render_params* p, bool pipelined) {
         a.tile_log2 = tile_log2;
         a.tiles_x = tiles_x;
         a.n_tiles = (int32_t)n_tiles;
-        a.pair64 = (spp == 64 && tile_log2 == 3 && c->stack_need <= rtk::PAIR64_STACK && !std::getenv("RT_NO_PAIR64")) ? 1 : 0;
+        a.pair64 = (spp == 64 && (tile_log2 == 3 || tile_log2 == 2) && c->stack_need <= rtk::PAIR64_STACK && !std::getenv("RT_NO_PAIR64")) ? 1 : 0;
         a.jitter = d_jitter;
         a.intensity = c->intensity.p;
         a.rgb = c->rgb.p;
@@ -1087,7 +1095,9 @@ int render_impl(rt_ctx* c, const rt_render_params* p, bool pipelined) {
         // finite coordinates => every node box (>= 1 triangle, rt_scene_build rejects empty meshes) has
         // min <= max, and so has its camera-relative copy (subtraction rounds monotonically): level 2
         a.pair64 = 0;  // 1 + log2(spp / 64) for spp = 64, 128, 256, ...: the one-pixel-per-batch instantiation
-        if (spp >= 64 && (spp & (spp - 1)) == 0 && tile_log2 == 3 && c->stack_need <= rtk::PAIR64_STACK &&
+        // (an even number of batches per wave: 16 or 4 pixels per wave, or one pixel of >= 128 samples)
+        if (spp >= 64 && (spp & (spp - 1)) == 0 && (tile_log2 == 3 || tile_log2 == 2 || (tile_log2 == 1 && spp >= 128)) &&
+            c->stack_need <= rtk::PAIR64_STACK &&
             !std::getenv("RT_NO_PAIR64"))
             for (int q = spp >> 6; q; q >>= 1) ++a.pair64;
         a.fast_ok = (c->max_abs_coord + std::fabs(ox) + std::fabs(oy) + std::fabs(oz)) < 1e100 ? 2 : 0;
