@@ -66,6 +66,9 @@ def workload(name):
         label = "configs[0]: simple_block.e surface (44 triangles), 400x225, 1 spp"
     else:
         raise SystemExit(f"unknown workload {name}")
+    if os.environ.get("RT_BENCH_SPP"):  # experiments only: the same scene at another sample count
+        spp = int(os.environ["RT_BENCH_SPP"])
+        label += f" [RT_BENCH_SPP={spp}]"
     cam = meshgen.camera_arrays(W, H)
     return label, coords, colors, cam, H, W, spp
 

@@ -996,6 +996,10 @@ int render_impl(rt_ctx* c, const rt_render_params* p, bool pipelined) {
         while (tile_log2 > 1 && int64_t((W + (1 << tile_log2) - 1) >> tile_log2) * ((rows + (1 << tile_log2) - 1) >> tile_log2) < 8192 &&
                (int64_t(1) << (2 * (tile_log2 - 1) - 2)) * spp >= 128)
             --tile_log2;
+    if (const char* e = std::getenv("RT_TILE_LOG2")) {  // tuning knob (packet kernels: 1..4, per-lane kernel: 3 or 4)
+        const int v = std::atoi(e);
+        if (v >= ((packet || (p->flags & RT_FLAG_FP32)) ? 1 : 3) && v <= 4) tile_log2 = v;
+    }
     const int ts = 1 << tile_log2;
     const int tiles_x = (W + ts - 1) / ts;
     const int tiles_y = (rows + ts - 1) / ts;
