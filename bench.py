@@ -410,7 +410,7 @@ def main():
         except Exception as e:
             philox = {"error": str(e)}
         cpu = None
-        if args.cpu_rays > 0:
+        if args.cpu_rays > 0 and world == 1:  # the CPU baseline is timed on rank 0 at N = 1 only
             frame(0)
             got = ctx.download(rgb=False, hit_ids=want_ids)
             if want_ids:
