@@ -23,4 +23,10 @@ timeout -s KILL 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_IN
 echo "sq pass ok"
 timeout -s KILL 300 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_sq2" -- $BENCH1 > "$OUT/pmc_sq2.log" 2>&1 || { echo "sq2 pass failed"; tail -5 "$OUT/pmc_sq2.log"; exit 0; }
 echo "sq2 pass ok"
+# scalar path: SMEM instruction count / time, scalar data cache hits and misses (the traversal's node and triangle
+# records are all scalar loads)
+timeout -s KILL 300 rocprofv3 --pmc SQ_INSTS_SMEM SQ_INST_CYCLES_SMEM SQ_INST_CYCLES_SALU SQ_WAIT_INST_LDS SQ_INSTS_BRANCH SQ_INST_LEVEL_SMEM --output-format csv -d "$OUT/pmc_sq3" -- $BENCH1 > "$OUT/pmc_sq3.log" 2>&1 || { echo "sq3 pass failed"; tail -5 "$OUT/pmc_sq3.log"; exit 0; }
+echo "sq3 pass ok"
+timeout -s KILL 300 rocprofv3 --pmc SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQC_TC_DATA_READ_REQ --output-format csv -d "$OUT/pmc_sqc" -- $BENCH1 > "$OUT/pmc_sqc.log" 2>&1 || { echo "sqc pass failed"; tail -5 "$OUT/pmc_sqc.log"; exit 0; }
+echo "sqc pass ok"
 find "$OUT" -name "*.csv" | head -40
