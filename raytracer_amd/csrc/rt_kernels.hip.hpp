@@ -751,6 +751,10 @@ struct PacketArgs {
     double* hit_t;
     unsigned long long* counters;
     int32_t pair64;   // host: 1 + log2(spp / 64) when spp = 64 * 2^n, tiles are 8x8 and stack_need <= PAIR64_STACK; else 0
+    // interleave: pixel i of wave w is Morton index 4 i + w of the tile, so the four waves of a workgroup walk a
+    // 2x2 pixel block at about the same time and meet each other's node and triangle lines in the scalar data
+    // cache (its 16 KB do not survive until the same wave's next pixel); 0: wave w owns the compact quadrant w
+    int32_t interleave;
     int32_t fast_ok;  // host: >= 1: every |node coordinate - camera| < 1e100; 2: and every box has min <= max
 };
 
@@ -807,8 +811,8 @@ constexpr int PAIR64_STACK = 32;   // stack entries left to the traversal in pai
 constexpr int PACKET_STACK = 128;  // entries of the per-wave LDS stack ({descriptor, lane mask}, 16 B each)
 static_assert((PACKET_STACK - PAIR64_STACK) * 16 >= 3 * 64 * 8, "the second pixel's colours must fit above the pair64 stack");
 
-// One workgroup = one square pixel tile, one wave = one quarter of the tile's pixels (a compact
-// quadrant in Morton order).  A wave walks its own pixels' samples 64 at a time and owns its part
+// One workgroup = one square pixel tile, one wave = one quarter of the tile's pixels (every fourth
+// pixel in Morton order, see PacketArgs::interleave; or a compact quadrant).  A wave walks its own pixels' samples 64 at a time and owns its part
 // of the accumulation, so waves never wait for each other: there is no workgroup barrier.
 // Rays are ordered pixel-major with the samples of a pixel innermost: at spp >= 64 the 64 lanes
 // of a wave are samples of ONE pixel, otherwise a compact block of neighbouring pixels.
@@ -835,7 +839,7 @@ __global__ __launch_bounds__(NT, 8) void render_packet_kernel(const PacketArgs a
     }
     const int ts = 1 << a.tile_log2;
     const int npix_w = (ts * ts) >> 2;  // pixels per wave: 16 (8x8 tile) or 64 (16x16 tile)
-    const int m0 = wv * npix_w;         // first Morton index of this wave's quadrant
+    const int m0 = wv * npix_w;         // first Morton index of this wave's quadrant (!interleave)
     int tix, tiy;
     tile_coords(tile, a.n_tiles, a.tiles_x, tix, tiy);
     const int tx0 = tix << a.tile_log2;
@@ -867,7 +871,7 @@ __global__ __launch_bounds__(NT, 8) void render_packet_kernel(const PacketArgs a
         const int rr = base + lane;
         const int ml = P64 ? (base >> (6 + lg64)) : rr / spp;  // P64: wave-uniform
         const int k = P64 ? (base & (spp - 1)) + lane : rr - ml * spp;
-        const int m = m0 + ml;
+        const int m = a.interleave ? (ml << 2) + wv : m0 + ml;
         q.px = tx0 + (int)compact1by1((uint32_t)m);
         q.py = ty0 + (int)compact1by1((uint32_t)m >> 1);
         q.active = (rr < n_rays) && (q.px < a.W) && (q.py < a.rows);
@@ -1091,7 +1095,7 @@ __global__ __launch_bounds__(NT, 8) void render_packet_kernel(const PacketArgs a
     }
 
     if (lane < npix_w) {
-        const int m = m0 + lane;
+        const int m = a.interleave ? (lane << 2) + wv : m0 + lane;
         const int px = tx0 + (int)compact1by1((uint32_t)m);
         const int py = ty0 + (int)compact1by1((uint32_t)m >> 1);
         if (px < a.W && py < a.rows) {

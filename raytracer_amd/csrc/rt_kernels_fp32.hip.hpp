@@ -139,6 +139,7 @@ struct Packet32Args {
     int32_t tile_log2;
     int32_t tiles_x, n_tiles;
     int32_t pair64;  // spp == 64 and stack_need <= rtk::PAIR64_STACK
+    int32_t interleave;  // see rtk::PacketArgs
     const double* jitter;
     double* intensity;
     uint8_t* rgb;
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(NT, 8) void render_packet32_kernel(const Packet32Ar
         const int rr = base + lane;
         const int ml = rr / spp;
         const int k = rr - ml * spp;
-        const int m = m0 + ml;
+        const int m = a.interleave ? (ml << 2) + wv : m0 + ml;
         q.px = tx0 + (int)rtk::compact1by1((uint32_t)m);
         q.py = ty0 + (int)rtk::compact1by1((uint32_t)m >> 1);
         q.active = (rr < n_rays) && (q.px < a.W) && (q.py < a.rows);
@@ -510,7 +511,7 @@ __global__ __launch_bounds__(NT, 8) void render_packet32_kernel(const Packet32Ar
     }
 
     if (lane < npix_w) {
-        const int m = m0 + lane;
+        const int m = a.interleave ? (lane << 2) + wv : m0 + lane;
         const int px = tx0 + (int)rtk::compact1by1((uint32_t)m);
         const int py = ty0 + (int)rtk::compact1by1((uint32_t)m >> 1);
         if (px < a.W && py < a.rows) {
