@@ -14,6 +14,8 @@ def main(src, dst):
     rows = []
     for f in glob.glob(src + "/pmc_*/**/*_counter_collection.csv", recursive=True):
         rows += list(csv.DictReader(open(f)))
+    if not rows:  # never replace a committed summary with an empty one (the GPU run may not have happened)
+        raise SystemExit(f"no counter files under {src}: nothing written")
     biggest = collections.defaultdict(int)
     for r in rows:
         k = r["Kernel_Name"].split("(")[0]
