@@ -1046,7 +1046,7 @@ int render_impl(rt_ctx* c, const rt_render_params* p, bool pipelined) {
         a.tiles_x = tiles_x;
         a.n_tiles = (int32_t)n_tiles;
         a.pair64 = (spp == 64 && (tile_log2 == 3 || tile_log2 == 2) && c->stack_need <= rtk::PAIR64_STACK && !std::getenv("RT_NO_PAIR64")) ? 1 : 0;
-        a.interleave = std::getenv("RT_NO_INTERLEAVE") ? 0 : 1;
+        a.interleave = (std::getenv("RT_NO_INTERLEAVE") || !a.pair64) ? 0 : 1;
         a.jitter = d_jitter;
         a.intensity = c->intensity.p;
         a.rgb = c->rgb.p;
@@ -1110,7 +1110,9 @@ int render_impl(rt_ctx* c, const rt_render_params* p, bool pipelined) {
             c->stack_need <= rtk::PAIR64_STACK &&
             !std::getenv("RT_NO_PAIR64"))
             for (int q = spp >> 6; q; q >>= 1) ++a.pair64;
-        a.interleave = std::getenv("RT_NO_INTERLEAVE") ? 0 : 1;
+        a.interleave = std::getenv("RT_NO_INTERLEAVE") ? 0 : (a.pair64 ? 1 : 0);
+        if (const char* e = std::getenv("RT_INTERLEAVE")) a.interleave = std::atoi(e);  // experiment: 0, 1, 2, 4, ...
+        if (a.interleave && ((a.interleave & (a.interleave - 1)) || a.interleave > ((1 << (2 * tile_log2)) >> 2))) a.interleave = 0;
         a.fast_ok = (c->max_abs_coord + std::fabs(ox) + std::fabs(oy) + std::fabs(oz)) < 1e100 ? 2 : 0;
         HIP_TRY(hipEventRecord(c->ev[0], c->stream));
         if (count && a.pair64)

@@ -807,6 +807,14 @@ __device__ __forceinline__ double rcp_exact(const double d) {  // 1.0 / d
     return __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
 }
 
+// Morton index (within the tile) of pixel i of wave w.  g = 0: wave w owns the compact quadrant starting at m0;
+// g = 2^k: the waves take turns every g pixels, so together they walk 4 g consecutive Morton indices at a time
+// (g = 1: a 2x2 block, one pixel each) and meet each other's lines in the scalar data cache.
+__device__ __forceinline__ int wave_pixel(const int i, const int w, const int m0, const int g) {
+    if (g == 0) return m0 + i;
+    return ((i & ~(g - 1)) << 2) + w * g + (i & (g - 1));
+}
+
 constexpr int PAIR64_STACK = 32;   // stack entries left to the traversal in pair64 mode (see render_packet_kernel)
 constexpr int PACKET_STACK = 128;  // entries of the per-wave LDS stack ({descriptor, lane mask}, 16 B each)
 static_assert((PACKET_STACK - PAIR64_STACK) * 16 >= 3 * 64 * 8, "the second pixel's colours must fit above the pair64 stack");
@@ -871,7 +879,7 @@ __global__ __launch_bounds__(NT, 8) void render_packet_kernel(const PacketArgs a
         const int rr = base + lane;
         const int ml = P64 ? (base >> (6 + lg64)) : rr / spp;  // P64: wave-uniform
         const int k = P64 ? (base & (spp - 1)) + lane : rr - ml * spp;
-        const int m = a.interleave ? (ml << 2) + wv : m0 + ml;
+        const int m = wave_pixel(ml, wv, m0, a.interleave);
         q.px = tx0 + (int)compact1by1((uint32_t)m);
         q.py = ty0 + (int)compact1by1((uint32_t)m >> 1);
         q.active = (rr < n_rays) && (q.px < a.W) && (q.py < a.rows);
@@ -1095,7 +1103,7 @@ __global__ __launch_bounds__(NT, 8) void render_packet_kernel(const PacketArgs a
     }
 
     if (lane < npix_w) {
-        const int m = a.interleave ? (lane << 2) + wv : m0 + lane;
+        const int m = wave_pixel(lane, wv, m0, a.interleave);
         const int px = tx0 + (int)compact1by1((uint32_t)m);
         const int py = ty0 + (int)compact1by1((uint32_t)m >> 1);
         if (px < a.W && py < a.rows) {

@@ -355,7 +355,7 @@ __global__ __launch_bounds__(NT, 8) void render_packet32_kernel(const Packet32Ar
         const int rr = base + lane;
         const int ml = rr / spp;
         const int k = rr - ml * spp;
-        const int m = a.interleave ? (ml << 2) + wv : m0 + ml;
+        const int m = rtk::wave_pixel(ml, wv, m0, a.interleave);
         q.px = tx0 + (int)rtk::compact1by1((uint32_t)m);
         q.py = ty0 + (int)rtk::compact1by1((uint32_t)m >> 1);
         q.active = (rr < n_rays) && (q.px < a.W) && (q.py < a.rows);
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(NT, 8) void render_packet32_kernel(const Packet32Ar
     }
 
     if (lane < npix_w) {
-        const int m = a.interleave ? (lane << 2) + wv : m0 + lane;
+        const int m = rtk::wave_pixel(lane, wv, m0, a.interleave);
         const int px = tx0 + (int)rtk::compact1by1((uint32_t)m);
         const int py = ty0 + (int)rtk::compact1by1((uint32_t)m >> 1);
         if (px < a.W && py < a.rows) {
