@@ -66,7 +66,7 @@ def random_case(rng):
         arr = cc[:, None, :] + rng.uniform(-0.6, 0.6, (cc.shape[0], 3, 3))
         coords, colors = [np.ascontiguousarray(arr[None])], [rng.uniform(0.0, 1.0, (1, cc.shape[0], 3))]
     W, H = int(rng.integers(1, 70)), int(rng.integers(1, 50))
-    spp = int(rng.choice([1, 2, 3, 5, 16, 33, 64, 100]))
+    spp = int(rng.choice([1, 2, 3, 5, 16, 33, 64, 100, 128]))
     if kind == 1:
         center = tuple(float(x) for x in rng.integers(-2, 3, 3))
         target = tuple(np.array(center) + np.array([0.0, 0.0, -1.0]))
