@@ -605,3 +605,15 @@ def test_64_spp_instantiation_equals_generic_and_is_skipped_for_deep_trees(ctx, 
         cam = (np.zeros(3), np.array([1e-6, 0.5, -3.0]), np.array([[2e-4, 0, 0], [0, -0.125, 0]]))
         got, want, _ = check_image(ctx, [cd], [kd], cam, 8, 16, 64)
         assert (want["hit_elem"] >= 0).mean() > 0.2
+
+
+def test_pipelined_driver_equals_unpipelined_at_64_spp(tmp_path):
+    """profiles/tools/soak_driver.py in small: the same 8-mesh / 2-camera / 64-spp job through the pipelined driver
+    (build-ahead, staged uploads, frame q+1 launched before frame q is read back) and, in a child process, with
+    RT_NO_PIPELINE=1 RT_BUILD_AHEAD=1: every P6 file byte-identical."""
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(__file__), "..", "profiles", "tools", "soak_driver.py")
+    r = subprocess.run([sys.executable, tool, "5", "512"], capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "all 10 files identical" in r.stdout
