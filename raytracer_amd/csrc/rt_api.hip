@@ -1080,15 +1080,11 @@ int render_impl(rt_ctx* c, const rt_render_params* p, bool pipelined) {
         a.sc.leaf_ext = c->leaf_ext.p;
         a.sc.tris = c->cam_tris.p;
         a.sc.colors = c->colors.p;
-        if ((rc = frame_params.ensure(1))) return rc;
         for (int i = 0; i < 3; ++i) {
-            h_frame_params.cam[i] = p->camera_center[i];
-            h_frame_params.p00[i] = p->pixel_00_center[i];
+            a.fpv.cam[i] = p->camera_center[i];
+            a.fpv.p00[i] = p->pixel_00_center[i];
         }
-        for (int i = 0; i < 6; ++i) h_frame_params.sp[i] = p->pixel_spacing[i];
-        HIP_TRY(hipMemcpyAsync(frame_params.p, &h_frame_params, sizeof(rtk::FrameParams), hipMemcpyHostToDevice,
-                               c->stream));
-        a.fp = frame_params.p;
+        for (int i = 0; i < 6; ++i) a.fpv.sp[i] = p->pixel_spacing[i];
         a.W = W;
         a.spp = spp;
         a.row0 = p->row_begin;

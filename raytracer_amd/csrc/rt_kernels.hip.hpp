@@ -739,7 +739,7 @@ struct FrameParams {
 
 struct PacketArgs {
     PacketScene sc;
-    const FrameParams* fp;
+    FrameParams fpv;  // camera block, read from the kernarg segment where it is used
     int32_t W, spp;
     int32_t row0, rows;
     int32_t tile_log2;
@@ -905,10 +905,11 @@ __global__ __launch_bounds__(NT, 8) void render_packet_kernel(const PacketArgs a
             // hoisted out of the loop it would hold 24 SGPRs across the traversal
             u32x16 fa;  // cam[0..2] p00[0..2] sp[0..1]
             u32x8 fb;   // sp[2..5]
-            const FrameParams* fpp = karg_ptr<const FrameParams, offsetof(PacketArgs, fp)>();
-            asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx8 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)"
+            // (the block travels in the kernel arguments themselves: no per-frame copy to the device)
+            const auto kseg = __builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx8 %1, %2, %4\n\ts_waitcnt lgkmcnt(0)"
                          : "=&s"(fa), "=&s"(fb)
-                         : "s"(fpp)
+                         : "s"(kseg), "i"(offsetof(PacketArgs, fpv)), "i"(offsetof(PacketArgs, fpv) + 0x40)
                          : "memory");
             const d2 jit = cs.jit;
             // cpp/rtrender.cpp:53-58
