@@ -60,7 +60,7 @@ def workload(name):
         # BASELINE.json configs[0]: simple_block.e, single mesh, single camera, 1 frame, no anti-aliasing
         from raytracer_amd import rtsimdataloader as loader
         m = loader.simdata_to_rtmesh(os.path.join(ROOT, "tests", "golden", "simple_block.e"), scale=100.0,
-                                     world_position=np.array([-0.5, -0.75, -2.0]))
+                                     world_position=np.array([-0.5, -0.75, -2.0]), color_field="disp_x")
         coords, colors = [m.node_coords_expanded_over_time[4:5].copy()], [m.face_colors_over_time[4:5].copy()]
         H, W, spp = 225, 400, 1
         label = "configs[0]: simple_block.e surface (44 triangles), 400x225, 1 spp"

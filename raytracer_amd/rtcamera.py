@@ -4,6 +4,14 @@ Host-side mirror of the reference's ``rtcamera.Camera`` (rtcamera.py:11-76): sam
 arguments, same attribute names, same floating-point evaluation order, so the values handed to
 ``cpp_render_scene`` are bit-identical (golden values: SURVEY.md section 8(c), tests/test_host_api.py).
 """
+if not __package__:  # imported as a TOP-LEVEL module (this directory on sys.path, the reference's own layout):
+    import importlib as _il  # become an alias of the package module so that there is one set of classes
+    import os as _os
+    import sys as _sys
+    _root = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+    if _root not in _sys.path:
+        _sys.path.append(_root)
+    _sys.modules[__name__] = _il.import_module("raytracer_amd." + __name__)
 from math import radians, tan
 
 import numpy as np

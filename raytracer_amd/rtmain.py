@@ -1,8 +1,16 @@
 """``render_scene``: the Python entry point, mirroring the reference's rtmain.py:6-29."""
+if not __package__:  # imported as a TOP-LEVEL module (this directory on sys.path, the reference's own layout):
+    import importlib as _il  # become an alias of the package module so that there is one set of classes
+    import os as _os
+    import sys as _sys
+    _root = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+    if _root not in _sys.path:
+        _sys.path.append(_root)
+    _sys.modules[__name__] = _il.import_module("raytracer_amd." + __name__)
 from pathlib import Path
 
-from .rtmaincpp import cpp_render_scene
-from .rtscene import RenderType, Scene
+from raytracer_amd.rtmaincpp import cpp_render_scene  # noqa: E402
+from raytracer_amd.rtscene import RenderType, Scene, find_max_displacements  # noqa: E402,F401  (rtmain.py:2)
 
 
 def render_scene(image_height: int, image_width: int, scene: Scene, antialiasing_samples: int,

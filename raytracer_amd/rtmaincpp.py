@@ -3,19 +3,34 @@
 ``cpp_render_scene`` keeps the ten positional arguments of the reference's export
 (cpp/rtmain.cpp:29-38, exported at :157-160, called from rtmain.py:29) and forwards them to the
 C ABI ``rt_render_scene`` of librtgpu.so, which runs the whole job on the GPU and writes
-``<out>/rtimage_<t>_cam<c>.ppm``.  To use it from the unmodified reference scripts put this
-package's directory ahead on sys.path (``import rtmaincpp`` then resolves to this file).
+``<out>/rtimage_<t>_cam<c>.ppm``.  Two ways to put it under the reference's unmodified
+``from rtmaincpp import cpp_render_scene`` (rtmain.py:4), both covered by tests/test_dropin.py:
+  * ``sys.path.insert(0, "<repo>/dropin")`` -- that directory holds ONLY an ``rtmaincpp`` module, so the
+    reference's own rtmain / rtscene / rtcamera keep resolving to the reference's files;
+  * ``sys.path.insert(0, "<repo>/raytracer_amd")`` -- ``rtmaincpp`` AND the mirrored rtmain / rtscene /
+    rtcamera / rtsimdataloader(_new) resolve here (for machines without pyvale); each of them then
+    aliases itself to its ``raytracer_amd.*`` twin, so there is one set of classes either way.
 
-Frame sharding over several processes (one per GPU) is opt-in: with RT_SHARD_FRAMES=1 the frames
-f = t*n_cameras + c with f % WORLD_SIZE == RANK are rendered on GPU LOCAL_RANK.
+Frame sharding over several processes (one per GPU) is opt-in: with RT_SHARD_FRAMES=1 rank RANK of
+WORLD_SIZE renders whole timesteps t % WORLD_SIZE == RANK (all cameras of a timestep, one host BVH build)
+on GPU LOCAL_RANK; with fewer timesteps than ranks, single frames f = t*n_cameras + c with
+f % WORLD_SIZE == RANK (the schedule is rt_shard_frames).
 """
+if not __package__:  # imported as a TOP-LEVEL module (this directory on sys.path, the reference's own layout):
+    import importlib as _il  # become an alias of the package module so that there is one set of classes
+    import os as _os
+    import sys as _sys
+    _root = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+    if _root not in _sys.path:
+        _sys.path.append(_root)
+    _sys.modules[__name__] = _il.import_module("raytracer_amd." + __name__)
 import ctypes as C
 import os
 
 import numpy as np
 
-from . import _lib as L
-from ._lib import lib
+from raytracer_amd import _lib as L  # noqa: E402
+from raytracer_amd._lib import lib  # noqa: E402
 
 
 def cpp_render_scene(image_height, image_width, number_of_samples, output_directory, timestep_count,

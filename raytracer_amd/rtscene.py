@@ -4,12 +4,20 @@ Host-side mirror of the reference's ``rtscene`` module (rtscene.py:8-126): the s
 names and the same clip / fill semantics, so scripts written against the reference keep working.
 Meshes are lists of per-mesh arrays: coordinates (T, E, 3, 3) and face colours (T, E, 3).
 """
+if not __package__:  # imported as a TOP-LEVEL module (this directory on sys.path, the reference's own layout):
+    import importlib as _il  # become an alias of the package module so that there is one set of classes
+    import os as _os
+    import sys as _sys
+    _root = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+    if _root not in _sys.path:
+        _sys.path.append(_root)
+    _sys.modules[__name__] = _il.import_module("raytracer_amd." + __name__)
 from dataclasses import dataclass, field
 from enum import Enum
 
 import numpy as np
 
-from .rtsimdataloader import RTMesh, SurfType  # noqa: F401  (same import the reference has, rtscene.py:4)
+from raytracer_amd.rtsimdataloader import RTMesh, SurfType  # noqa: E402,F401  (same import the reference has, rtscene.py:4)
 
 
 class RenderType(Enum):

@@ -14,6 +14,14 @@ PARITY: unpinned against pyvale/pyvista (triangle ORDER and winding choices insi
 observable here); what the reference's own files pin is checked in tests/test_loaders.py -- 44 surface
 triangles / (132, 3) expanded nodes for simple_block.e (rttests.py:154,170), 4992 triangles for the sphere.
 """
+if not __package__:  # imported as a TOP-LEVEL module (this directory on sys.path, the reference's own layout):
+    import importlib as _il  # become an alias of the package module so that there is one set of classes
+    import os as _os
+    import sys as _sys
+    _root = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+    if _root not in _sys.path:
+        _sys.path.append(_root)
+    _sys.modules[__name__] = _il.import_module("raytracer_amd." + __name__)
 from dataclasses import dataclass
 from enum import Enum, IntEnum
 from pathlib import Path
@@ -60,8 +68,9 @@ class RTMesh:
     nodes_per_element: int = 3
 
     def set_surface(self, surface_type=SurfType.FIELD_COLOR, surface_fill=None, uv_coords=None):
-        """Field colours: a single RGB (3,), per element (E,3) or per timestep (T,E,3); anything else (or
-        nothing) pre-fills mid grey 0.5 with the reference's messages (rtsimdataloader_new.py:58-86)."""
+        """Field colours: a single RGB (3,) or per timestep (T,E,3); anything else (or nothing) pre-fills mid
+        grey 0.5 with the reference's messages (rtsimdataloader_new.py:58-86) -- including, as in the reference,
+        a per-element (E,3) fill, whose branch falls through to the grey fill."""
         if self.surface_type is not None and surface_type != self.surface_type:
             self.face_colors_over_time = self.uvs_over_time = self.texture = self.uvs = None
         self.surface_type = surface_type
@@ -73,8 +82,9 @@ class RTMesh:
                 self.face_colors_over_time = np.ones(shape_te) * surface_fill
                 return
             elif surface_fill.shape == (self.element_count, RGB_VALS):
+                # bug-compatible: the reference's branch has no `return` (rtsimdataloader_new.py:76-78), so the
+                # broadcast colours are overwritten by the grey fill below
                 self.face_colors_over_time = np.ascontiguousarray(np.broadcast_to(surface_fill[np.newaxis], shape_te))
-                return
             elif surface_fill.shape == shape_te:
                 self.face_colors_over_time = surface_fill
                 return
@@ -169,8 +179,12 @@ def tet_boundary_faces(coords, tets):
 
 
 def simdata_to_rtmesh(pypath: Path, field_components=("disp_x", "disp_y", "disp_z"), fields_to_render=("disp_y", "disp_x"),
-                      scale: float = 100.0, world_position=None, world_rotation=None, color_field="disp_x"):
-    """Exodus file -> RTMesh with the surface triangles over all timesteps and x-displacement grey colours."""
+                      scale: float = 100.0, world_position=None, world_rotation=None, color_field=None):
+    """Exodus file -> RTMesh with the surface triangles over all timesteps.  Like the reference
+    (rtsimdataloader_new.py:117-180) it leaves ``surface_type`` unset and fills no colours -- call
+    ``set_surface`` next.  ``color_field="disp_x"`` (no counterpart in rtsimdataloader_new) additionally fills
+    the min-max normalised nodal-field greys of the reference's older loader (rtsimdataloader.py:29-35,64-75)
+    and sets FIELD_COLOR."""
     ex = read_exodus(pypath)
     coords = ex["coords"] * scale
     T = len(ex["times"])
@@ -188,11 +202,11 @@ def simdata_to_rtmesh(pypath: Path, field_components=("disp_x", "disp_y", "disp_
     over_time = np.empty((T,) + coords.shape)
     expanded = np.empty((T, conn.shape[0], 3, 3))
     colors = np.empty((T, conn.shape[0], 3))
+    field = ex["nodal"].get(color_field) if color_field else None
     for t in range(T):
         nodes = orient_mesh_in_world(coords + (disp[t] if t > 0 else 0.0), world_position, world_rotation)
         over_time[t] = nodes
         expanded[t] = nodes[conn]
-        field = ex["nodal"].get(color_field)
         if t == 0 or field is None or field[t].max() == field[t].min():
             colors[t] = 0.5
         else:
@@ -200,15 +214,16 @@ def simdata_to_rtmesh(pypath: Path, field_components=("disp_x", "disp_y", "disp_
     mesh.node_coords = over_time[0]
     mesh.node_coords_over_time = over_time
     mesh.node_coords_expanded_over_time = expanded
-    mesh.face_colors_over_time = colors
-    mesh.surface_type = SurfType.FIELD_COLOR
+    if color_field:
+        mesh.face_colors_over_time = colors
+        mesh.surface_type = SurfType.FIELD_COLOR
     return mesh
 
 
 def add_mesh_to_scene(scene, pypath: Path, field_components=("disp_x", "disp_y", "disp_z"),
                       fields_to_render=("disp_y", "disp_x"), world_position=None, scale: float = 100.0):
     """Exodus file -> Scene.add_mesh(...) with data for all timesteps (reference: rtsimdataloader.py:43-83)."""
-    m = simdata_to_rtmesh(pypath, field_components, fields_to_render, scale, world_position)
+    m = simdata_to_rtmesh(pypath, field_components, fields_to_render, scale, world_position, color_field=field_components[0])
     scene.add_mesh(m.node_coords_expanded_over_time, m.node_coords, m.connectivity, m.face_colors_over_time,
                    m.timestep_count)
 

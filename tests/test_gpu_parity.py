@@ -368,7 +368,7 @@ def test_reference_sample_files_render_like_the_oracle(ctx, tmp_path):
     assert 0.05 < (want["hit_elem"] >= 0).mean() < 0.9
     # configs[0], every timestep
     b = loader.simdata_to_rtmesh(os.path.join(gold, "simple_block.e"), scale=100.0,
-                                 world_position=np.array([-0.5, -0.75, -2.0]))
+                                 world_position=np.array([-0.5, -0.75, -2.0]), color_field="disp_x")
     for t in (0, 4, 8):
         got, want, _ = check_image(ctx, [b.node_coords_expanded_over_time], [b.face_colors_over_time],
                                    meshgen.camera_arrays(100, 56), 56, 100, 1, timestep=t)

@@ -20,7 +20,7 @@ def signed_volume(tris):
 
 
 def test_exodus_block_surface():
-    m = L.simdata_to_rtmesh(BLOCK, scale=100.0)
+    m = L.simdata_to_rtmesh(BLOCK, scale=100.0, color_field="disp_x")
     assert m.element_count == 44 and m.timestep_count == 9
     assert m.node_coords_expanded_over_time.shape == (9, 44, 3, 3)
     assert m.node_coords_expanded_over_time[0].reshape(-1, 3).shape == (132, 3)
@@ -65,3 +65,20 @@ def test_reader_errors(tmp_path):
     bad.write_text("# vtk DataFile Version 2.0\nx\nBINARY\nDATASET UNSTRUCTURED_GRID\n")
     with pytest.raises(ValueError):
         L.vtk_mesh_to_rtmesh(bad)
+
+
+def test_reference_quirks_of_the_new_loader_are_kept():
+    """rtsimdataloader_new.py:76-86: the per-element (E,3) branch of set_surface has no `return`, so the fill
+    ends up grey; rtsimdataloader_new.py:117-180: simdata_to_rtmesh sets no surface, and Scene.add_rtmesh
+    (rtscene.py:44-55) then prints its message and adds no coordinates."""
+    m = L.simdata_to_rtmesh(BLOCK, scale=100.0)
+    assert m.surface_type is None and m.face_colors_over_time is None
+    sc = ra.Scene()
+    sc.add_rtmesh(m)
+    assert len(sc.coords_expanded) == 0 and len(sc.face_colors) == 0
+    per_elem = np.tile(np.array([0.1, 0.2, 0.3]), (m.element_count, 1))
+    m.set_surface(L.SurfType.FIELD_COLOR, per_elem)
+    assert m.face_colors_over_time.shape == (9, 44, 3) and np.all(m.face_colors_over_time == 0.5)
+    per_step = np.ones((9, 44, 3)) * 0.25
+    m.set_surface(L.SurfType.FIELD_COLOR, per_step)
+    assert m.face_colors_over_time is per_step
