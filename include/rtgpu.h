@@ -34,6 +34,11 @@ typedef struct rt_scene rt_scene; /* host-side acceleration structure of ONE tim
 const char *rt_last_error(void);
 const char *rt_version(void);
 int rt_device_count(void);
+/* Host threads this process uses for the BVH build pool (and the host jump-state helper): RT_HOST_THREADS if
+ * set, else the cores the process may run on divided by LOCAL_WORLD_SIZE (ranks on this node), clamped to
+ * 1..16.  OMP_NUM_THREADS is ignored on purpose (torchrun sets it to 1 for multi-rank jobs).  The reference
+ * has one thread; no counterpart. */
+int rt_host_threads(void);
 
 /* ------------------------------------------------------------------ */
 /* Host BVH build + flatten.                                           */
@@ -45,8 +50,8 @@ int rt_device_count(void);
 /*   elem_counts[m] = E_m (the reference reads it from                 */
 /*   face_colors.shape(1), rtbvh.cpp:615).  E_m >= 1.                  */
 /* n_threads: meshes are built concurrently on up to n_threads host    */
-/* threads (<= 0: one per mesh, capped at 16); results do not depend   */
-/* on it.                                                              */
+/* threads (<= 0: one per mesh, capped at rt_host_threads()); results  */
+/* do not depend on it.                                                */
 /* ------------------------------------------------------------------ */
 rt_scene *rt_scene_build(int n_meshes, const double *const *coords, const double *const *colors,
                          const int64_t *elem_counts, int timestep, int n_threads);

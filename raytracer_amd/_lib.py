@@ -51,6 +51,7 @@ _PROTOS = {
     "rt_last_error": (C.c_char_p, []),
     "rt_version": (C.c_char_p, []),
     "rt_device_count": (C.c_int, []),
+    "rt_host_threads": (C.c_int, []),
     "rt_scene_build": (_VP, [C.c_int, C.POINTER(_VP), C.POINTER(_VP), _VP, C.c_int, C.c_int]),
     "rt_scene_free": (None, [_VP]),
     "rt_scene_info": (C.c_int, [_VP, C.POINTER(SceneInfo)]),

@@ -47,17 +47,6 @@ double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-int host_threads() {
-    const char* e = std::getenv("RT_HOST_THREADS");
-    int n = e ? std::atoi(e) : 0;
-    if (n <= 0) {
-        const char* omp = std::getenv("OMP_NUM_THREADS");
-        n = omp ? std::atoi(omp) : 0;
-    }
-    if (n <= 0) n = 8;
-    return std::min(n, 64);
-}
-
 template <typename T>
 struct DevBuf {
     T* p = nullptr;
@@ -506,6 +495,8 @@ extern "C" {
 const char* rt_last_error(void) { return g_err.c_str(); }
 const char* rt_version(void) { return "rtgpu 0.1 (gfx950, fp64 parity path)"; }
 
+int rt_host_threads(void) { return rt::host_threads(); }
+
 int rt_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -629,7 +620,7 @@ int rt_mt19937_stream_states(uint32_t seed, uint64_t base_position, uint64_t str
         rt::mt_seed(s, seed);
         rt::mt_apply(rt::mt_jump_poly(base_position), s, b);
         std::vector<rt::MtState> out;
-        rt::mt_stream_states(b, stride, n, host_threads(), out);
+        rt::mt_stream_states(b, stride, n, rt::host_threads(), out);
         std::memcpy(states, out.data(), size_t(n) * sizeof(rt::MtState));
         return RT_OK;
     } catch (const std::exception& e) {

@@ -17,6 +17,8 @@
 // `int` strides overflow past 2^31 doubles).
 #include "rt_bvh.hpp"
 
+#include <sched.h>
+
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -88,21 +90,31 @@ struct Elements {
 // serial loop uses, so the outcome is bit-identical to the serial pass (first occurrence wins
 // among equal values, which also fixes the sign of a zero) whatever the thread count.
 // ---------------------------------------------------------------------------------------
-int pool_threads() {
-    const char* e = std::getenv("RT_HOST_THREADS");
-    int n = e ? std::atoi(e) : 0;
-    if (n <= 0) {
-        const char* omp = std::getenv("OMP_NUM_THREADS");
-        n = omp ? std::atoi(omp) : 0;
+}  // namespace
+// One helper for every host-side pool (BVH build, host jump states).  RT_HOST_THREADS wins; otherwise the
+// cores this process may run on (sched_getaffinity) divided among the ranks of this node (LOCAL_WORLD_SIZE,
+// set by torchrun), 1..16.  OMP_NUM_THREADS is deliberately NOT consulted: torchrun exports OMP_NUM_THREADS=1
+// to multi-rank jobs, and a rank that built its trees on one thread would be host-bound (hard part 3).
+int host_threads() {
+    if (const char* e = std::getenv("RT_HOST_THREADS")) {
+        const int n = std::atoi(e);
+        if (n > 0) return std::min(n, 64);
     }
-    if (n <= 0) n = static_cast<int>(std::thread::hardware_concurrency());
-    return std::max(1, std::min(n, 16));
+    int cores = 0;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) cores = CPU_COUNT(&set);
+    if (cores <= 0) cores = static_cast<int>(std::thread::hardware_concurrency());
+    int ranks = 1;
+    if (const char* e = std::getenv("LOCAL_WORLD_SIZE")) ranks = std::max(1, std::atoi(e));
+    return std::max(1, std::min(cores / ranks, 16));
 }
+namespace {
 
 class Pool {
 public:
     static Pool& get() {
-        static Pool p(pool_threads() - 1);
+        static Pool p(host_threads() - 1);
         return p;
     }
     int width() const { return static_cast<int>(workers_.size()) + 1; }
@@ -651,7 +663,7 @@ Scene* build_scene(int n_meshes, const double* const* coords, const double* cons
         const int64_t E = elem_counts[m];
         build_one_blas(blases[m], m, coords[m] + static_cast<int64_t>(timestep) * E * 9, E, mesh_cent[m]);
     };
-    int nt = n_threads <= 0 ? std::min(n_meshes, 16) : std::min(n_threads, n_meshes);
+    int nt = n_threads <= 0 ? std::min(n_meshes, host_threads()) : std::min(n_threads, n_meshes);
     if (nt <= 1) {
         for (int m = 0; m < n_meshes; ++m) work(m);
     } else {

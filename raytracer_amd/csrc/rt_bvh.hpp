@@ -11,6 +11,10 @@
 
 namespace rt {
 
+// Host threads of every host-side pool of this library (see rt_bvh.cpp; RT_HOST_THREADS, else affinity cores /
+// LOCAL_WORLD_SIZE, 1..16; never OMP_NUM_THREADS).
+int host_threads();
+
 // ---- host tree in the reference's numbering (kept for introspection / parity tests) ----
 struct HostNode {
     double mn[3], mx[3];

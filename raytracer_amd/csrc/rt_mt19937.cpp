@@ -162,7 +162,7 @@ void mt_next_block(MtState& s) {
 
 constexpr size_t kMaxCachedPolys = 4096;  // 10 MB
 
-const MtPoly& mt_jump_poly(uint64_t stride) {
+MtPoly mt_jump_poly(uint64_t stride) {
     {
         std::lock_guard<std::mutex> lk(g_cache_mu);
         auto it = g_cache.find(stride);
@@ -192,14 +192,10 @@ const MtPoly& mt_jump_poly(uint64_t stride) {
         }
     }
     std::lock_guard<std::mutex> lk(g_cache_mu);
-    // references into the map are handed out, so entries are never evicted: past the bound the result is
-    // returned through a per-thread slot instead (valid until this thread's next call), 2.5 KB per entry
-    if (g_cache.size() >= kMaxCachedPolys) {
-        thread_local MtPoly overflow;
-        overflow = r;
-        return overflow;
-    }
-    return g_cache.emplace(stride, r).first->second;
+    // results are returned by value (2.5 KB), so a full cache just stops growing: callers that hold several
+    // polynomials at once (mt_stream_states) can never see one overwritten by the next call
+    if (g_cache.size() < kMaxCachedPolys) g_cache.emplace(stride, r);
+    return r;
 }
 
 void mt_apply(const MtPoly& g, const MtState& in, MtState& out) {
@@ -230,20 +226,20 @@ void mt_stream_states(const MtState& base, uint64_t stride, int n, int n_threads
     if (n <= 1) return;
     int levels = 0;
     while ((1 << levels) < n) ++levels;
-    std::vector<const MtPoly*> polys(static_cast<size_t>(levels));
-    for (int k = 0; k < levels; ++k) polys[k] = &mt_jump_poly(stride << k);  // ascending: reuses squarings
+    std::vector<MtPoly> polys(static_cast<size_t>(levels));
+    for (int k = 0; k < levels; ++k) polys[k] = mt_jump_poly(stride << k);  // ascending: reuses squarings
     for (int k = levels - 1; k >= 0; --k) {
         const int step = 1 << k;
         std::vector<int> srcs;
         for (int r = 0; r + step < n; r += 2 * step) srcs.push_back(r);
         const int nt = std::max(1, std::min<int>(n_threads, static_cast<int>(srcs.size())));
         if (nt == 1) {
-            for (int r : srcs) mt_apply(*polys[k], out[r], out[r + step]);
+            for (int r : srcs) mt_apply(polys[k], out[r], out[r + step]);
         } else {
             std::vector<std::thread> pool;
             for (int w = 0; w < nt; ++w)
                 pool.emplace_back([&, w]() {
-                    for (size_t q = w; q < srcs.size(); q += nt) mt_apply(*polys[k], out[srcs[q]], out[srcs[q] + step]);
+                    for (size_t q = w; q < srcs.size(); q += nt) mt_apply(polys[k], out[srcs[q]], out[srcs[q] + step]);
                 });
             for (auto& th : pool) th.join();
         }

@@ -31,7 +31,7 @@ struct MtPoly {
 };
 
 // g = x^stride mod phi  (cached per stride; thread-safe)
-const MtPoly& mt_jump_poly(uint64_t stride);
+MtPoly mt_jump_poly(uint64_t stride);
 // out = g(A) in   (out may alias in)
 void mt_apply(const MtPoly& g, const MtState& in, MtState& out);
 

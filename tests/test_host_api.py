@@ -1,6 +1,7 @@
 """Host-side mirror of the reference's Python interface: Camera golden values (SURVEY.md section 8(c),
 captured from the reference's rtcamera.py), Scene clip / fill semantics (rtscene.py:57-110) and the
 render_scene argument plumbing (rtmain.py:6-29).  CPU only: the C++ backend is replaced by a recorder."""
+import os
 import numpy as np
 
 import raytracer_amd as ra
@@ -75,3 +76,28 @@ def test_render_scene_plumbing(monkeypatch, tmp_path, capsys):
     ra.Camera(8, 4).add_camera_to_scene(sc)
     rtmain.render_scene(4, 8, sc, 1, tmp_path, render_type=RenderType.STATIC)
     assert calls[-1][4] == 1
+
+
+def _threads_in_child(env_extra):
+    """rt_host_threads() of a fresh process (the pool size is fixed at first use) under the given environment."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RT_HOST_THREADS", "OMP_NUM_THREADS", "LOCAL_WORLD_SIZE")}
+    env.update(env_extra)
+    code = f"import sys; sys.path.insert(0, {root!r}); from raytracer_amd import _lib as L; print(L.lib.rt_host_threads())"
+    return int(subprocess.check_output([sys.executable, "-c", code], env=env, timeout=120).decode().split()[-1])
+
+
+def test_host_pool_does_not_inherit_torchruns_omp_num_threads():
+    """torchrun exports OMP_NUM_THREADS=1 to multi-rank jobs; the per-timestep host BVH build decides the
+    multi-GPU frame rate (hard part 3), so a rank takes affinity cores / LOCAL_WORLD_SIZE instead."""
+    cores = len(os.sched_getaffinity(0))
+    assert _threads_in_child({"OMP_NUM_THREADS": "1"}) == max(1, min(cores, 16))
+    assert _threads_in_child({"OMP_NUM_THREADS": "1", "LOCAL_WORLD_SIZE": "2"}) == max(1, min(cores // 2, 16))
+    assert _threads_in_child({"OMP_NUM_THREADS": "1", "LOCAL_WORLD_SIZE": "8"}) == max(1, min(cores // 8, 16))
+    if cores >= 4:
+        assert _threads_in_child({"OMP_NUM_THREADS": "1", "LOCAL_WORLD_SIZE": "2"}) > 1
+    if cores >= 16:  # a many-core box: 8 ranks under torchrun still build on more than one thread each
+        assert _threads_in_child({"OMP_NUM_THREADS": "1", "LOCAL_WORLD_SIZE": "8"}) > 1
+    assert _threads_in_child({"RT_HOST_THREADS": "3", "OMP_NUM_THREADS": "1", "LOCAL_WORLD_SIZE": "8"}) == 3

@@ -61,3 +61,22 @@ def test_other_seed():
     r = orc.Rng(12345)
     r.discard(5000)
     assert np.array_equal(oracle_words_from_state(st, 100), r.u32(100))
+
+
+def test_stream_states_stay_correct_once_the_polynomial_cache_is_full():
+    """The host cache of jump polynomials stops growing at 4096 entries.  mt_stream_states holds one polynomial
+    per doubling level at the same time; they must stay distinct when none of them can be cached any more
+    (a long-lived process seeking to many distinct positions fills the cache)."""
+    for p in range(1, 4300):  # 4299 distinct distances: more than the cache holds
+        ra.mt19937_state_at(p)
+    base, stride, n = 1234, 5 * 624, 9  # 4 doubling levels, none of their strides cached
+    states = ra.mt19937_stream_states(base, stride, n)
+    for r in range(n):
+        g = orc.Rng(5489)
+        g.discard(base + r * stride)
+        assert np.array_equal(oracle_words_from_state(states[r], 64), g.u32(64)), r
+    # and a single state after the fill
+    st = ra.mt19937_state_at(987654)
+    g = orc.Rng(5489)
+    g.discard(987654)
+    assert np.array_equal(oracle_words_from_state(st, 64), g.u32(64))

@@ -131,3 +131,32 @@ def test_shading_and_quantise(gold):
                                     int(gold["quant_spp"][q]), orc.C.byref(inten))
         assert byte == int(gold["quant_byte"][q])
         assert bits([inten.value])[0] == bits([gold["quant_intensity"][q]])[0]
+
+
+# ---- the only whole-path evidence that comes from the compiled reference ------------------------------------
+# SURVEY.md 6 / 8(d) [probed]: the reference's own rtbvh.cpp + rtrayintersection.cpp, compiled in the survey
+# container, on the 1,048,352-triangle bumped plate (camera at the origin, fov 90, 256 x 256, 1 spp, jittered from
+# mt19937(5489)) visited 43.9 TLAS+BLAS nodes (42.9 BLAS + 1 TLAS) and tested 4.39 triangles per ray, 0.906 of the
+# rays hit.  These three numbers depend on the BUILDER (tree shape: split axis / bin / partition decisions) and on
+# the TRAVERSAL (visit rule, no culling) together, which nothing else reference-derived pins.  The survey quotes
+# three significant digits, hence the tolerances.
+SURVEY_NODES_PER_RAY, SURVEY_TRIS_PER_RAY, SURVEY_HIT_RATE = 43.9, 4.39, 0.906
+
+
+def survey_plate():
+    from raytracer_amd import meshgen
+    c, k = meshgen.plate(724)  # SURVEY 8(d) "Plate": n x n quads, z = z0 + 0.05 L sin(7x/L) cos(5y/L), L = 10
+    assert c.shape[1] == 1048352
+    return c, k, meshgen.camera_arrays(256, 256), 256, 256, 1
+
+
+def check_survey_stats(nodes, tris, hits, rays):
+    assert abs(nodes / rays - SURVEY_NODES_PER_RAY) <= 0.005 * SURVEY_NODES_PER_RAY, nodes / rays
+    assert abs(tris / rays - SURVEY_TRIS_PER_RAY) <= 0.01 * SURVEY_TRIS_PER_RAY, tris / rays
+    assert abs(hits / rays - SURVEY_HIT_RATE) <= 0.001, hits / rays
+
+
+def test_oracle_visit_statistics_equal_the_surveys_probe_of_the_compiled_reference():
+    c, k, cam, H, W, spp = survey_plate()
+    w = orc.Scene([c], [k]).render(*cam, H, W, spp, rng=orc.Rng())
+    check_survey_stats(w["nodes"], w["tris"], w["hits"], H * W * spp)
