@@ -27,7 +27,34 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+# fp64 VALU issue peak WITHOUT fma (-ffp-contract=off, the parity contract): 256 CU x 4 SIMD x 16 lanes x 2.4 GHz
+# = 39.3 T lane-operations/s (MI355X_MICROARCH.md: 78.6 TFLOP/s fp64 vector counts an fma as two)
+FP64_LANE_OPS_PEAK = 256 * 4 * 16 * 2.4e9
 TDEV = "cuda"  # device of the tensors handed to torch.distributed (see RT_BENCH_BACKEND)
+
+
+def kernel_source_hash():
+    """sha256 over the sources that determine the kernels' instruction streams.  profiles/summarize_pmc.py stores
+    it with every PMC summary; the bench refuses to price a launch with counters taken from other kernels."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in ("raytracer_amd/csrc/rt_kernels.hip.hpp", "raytracer_amd/csrc/rt_kernels_fp32.hip.hpp",
+                "raytracer_amd/csrc/rt_bvh.hpp", "raytracer_amd/csrc/Makefile"):
+        h.update(open(os.path.join(ROOT, rel), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def launch_ranks(n):
+    """`--gpus N` without a launcher: start the N ranks ourselves as fresh child processes (this process has not
+    touched the GPU and never will) and return their exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
 
 
 def workload(name):
@@ -202,6 +229,26 @@ def bench_multiframe(ra, rank, world, local_rank, dist, steps_per_rank=16):
             "includes": "per-timestep host BVH build (overlapped), upload, render, read-back, P6 write"}
 
 
+def rehearse(rank, world, local_rank):
+    """The N > 1 launch path on CPUs: rendezvous (gloo, 127.0.0.1), every rank's host thread count and its share of
+    a frame sequence and of one banded frame, gathered on rank 0 and printed as one JSON line.  No GPU call."""
+    import torch.distributed as dist
+    import raytracer_amd as ra
+    from raytracer_amd import _lib as L
+    dist.init_process_group("gloo")
+    H, W, spp, T, n_cam = 4096, 4096, 64, 100, 2
+    frames, pos = ra.shard_frames(T, n_cam, rank, world, 0, H * W * spp * 4)
+    mine = {"rank": rank, "local_rank": local_rank, "host_threads": int(L.lib.rt_host_threads()),
+            "omp_num_threads_env": os.environ.get("OMP_NUM_THREADS"), "frames": [int(f) for f in frames],
+            "band": list(ra.shard_rows(H, W, spp, rank, world, 0))[:2]}
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine)
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"rehearsal": True, "n_gpus": world, "ranks": everyone}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -211,13 +258,31 @@ def main():
     ap.add_argument("--cpu-rays", type=float, default=40e6, help="rays in the CPU-baseline sample, about 10 s of one core (0 = skip)")
     ap.add_argument("--no-hit-ids", action="store_true")
     ap.add_argument("--no-multiframe", action="store_true", help="skip the frames/s (multi-frame driver) measurement")
+    ap.add_argument("--lean", action="store_true",
+                    help="timed loop + roofline only (no CPU baseline, driver legs, fp32 / Philox legs): profiling runs")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="N > 1 launch path without a GPU: ranks rendezvous over gloo, report their shard schedules and "
+                         "host thread counts, and exit (CPU test of the launcher)")
     args = ap.parse_args()
+    if args.lean:
+        args.cpu_rays = 0
+        args.no_multiframe = True
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # not under a launcher: become one.  Nothing above has touched the GPU (numpy only), the ranks are
+        # fresh child processes, and this process exits with their code.
+        raise SystemExit(launch_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with `python bench.py --gpus {args.gpus}` "
+                         f"(starts the ranks itself) or `python -m torch.distributed.run --nproc-per-node {args.gpus} "
+                         f"bench.py --gpus {args.gpus}`")
+    if args.rehearse:
+        return rehearse(rank, world, local_rank)
     dist = None
     if world > 1:
         import torch
@@ -264,22 +329,19 @@ def main():
     for s in range(args.warmup):
         frame(s)
     barrier()
-    kernel_ms = []
-    jitter_ms = []
+    # kernel time of exactly the timed launches: the library adds every launch's HIP-event time (events on the
+    # kernel's own stream) to a running total when the NEXT rt_render finds it complete, so no per-step sync
+    before = ctx.stats()
     t0 = time.perf_counter()
     for s in range(args.steps):
         frame(args.warmup + s)
-        # stats of the PREVIOUS launch would stall the pipeline; collect after the loop for the last one,
-        # and per step only when the render has to be waited for anyway (rt_render syncs at entry)
-        st = None
-        if s == args.steps - 1:
-            ctx.sync()
-            st = ctx.stats()
-        if st:
-            kernel_ms.append(st["render_kernel_ms"])
-            jitter_ms.append(st["jitter_kernel_ms"])
     barrier()
     elapsed = time.perf_counter() - t0
+    after = ctx.stats()
+    timed_launches = after["render_launches_timed"] - before["render_launches_timed"]
+    kernel_ms_timed = ((after["render_kernel_ms_total"] - before["render_kernel_ms_total"]) / timed_launches
+                       if timed_launches == args.steps else None)
+    jitter_ms_last = after["jitter_kernel_ms"]
     if dist is not None:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64, device=TDEV)
@@ -293,31 +355,40 @@ def main():
 
     # N > 1 only: ONE frame of the same workload split into row bands over the ranks (SURVEY 8(e), strong
     # scaling): every rank renders its band at its own stream position, then the bands are gathered on rank 0
-    # (RCCL gather of the f64 intensity bands).  Reported in aux, never part of `value`.
+    # (RCCL gather of the f64 intensity bands).  Reported in aux, never part of `value`.  A rank that fails
+    # must not leave its peers blocked in a collective: the ranks first agree (all_reduce of an error flag)
+    # that every local phase succeeded, and only then enter the gather.
     banded = None
     if world > 1:
+        import torch
+        r0, r1, pos = ra.shard_rows(H, W, spp, rank, world, 0)
+        sizes = [ra.shard_rows(H, W, spp, r, world, 0) for r in range(world)]
+        err, t_render, band = "", 0.0, None
         try:
-            import torch
-            r0, r1, pos = ra.shard_rows(H, W, spp, rank, world, 0)
-
             def band_step():
                 if r1 > r0:
                     ctx.rng_seek(pos)
                     ctx.render(*cam, H, W, spp, rows=(r0, r1), hit_ids=want_ids)
 
             band_step()
-            barrier()
+            ctx.sync()
             t0 = time.perf_counter()
             for _ in range(args.steps):
                 band_step()
-            barrier()
+            ctx.sync()
             t_render = (time.perf_counter() - t0) / args.steps
             t0 = time.perf_counter()
             band = ctx.download(rgb=False, hit_ids=False)["intensity"] if r1 > r0 else np.empty((0, W))
-            sizes = [ra.shard_rows(H, W, spp, r, world, 0) for r in range(world)]
+        except Exception as e:  # local work only: no collective inside this block
+            err = f"rank {rank}: {e}"
+        flag = torch.tensor([1.0 if err else 0.0], dtype=torch.float64, device=TDEV)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if float(flag.item()) > 0.0:
+            banded = {"error": err or "another rank failed in the banded leg"}
+        else:
             pad = max(b - a for a, b, _ in sizes)
             mine = torch.zeros(pad, W, dtype=torch.float64, device=TDEV)
-            mine[: r1 - r0] = torch.from_numpy(band).to(TDEV)
+            mine[: r1 - r0] = torch.from_numpy(np.ascontiguousarray(band)).to(TDEV)
             parts = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
             dist.gather(mine, parts, dst=0)
             torch.cuda.synchronize()
@@ -327,42 +398,78 @@ def main():
             banded = {"ms_per_frame_render": float(tt[0]) * 1e3, "mrays_per_s": rays_per_frame / float(tt[0]) / 1e6,
                       "download_plus_gather_ms": float(tt[1]) * 1e3, "bands": [[a, b] for a, b, _ in sizes],
                       "scaling": "strong"}
-        except Exception as e:
-            banded = {"error": str(e)}
 
-    # untimed extras on rank 0: per-launch kernel time over several launches, visit counters, CPU baseline
+    # untimed extras on rank 0: visit counters, roofline, hand-over costs, CPU baseline
     out = None
     if rank == 0:
-        ks = []
-        for s in range(max(2, min(args.steps, 3))):
-            frame(0)
-            ctx.sync()
-            ks.append(ctx.stats())
-        kms = float(np.mean([k["render_kernel_ms"] for k in ks]))
-        jms = float(np.mean([k["jitter_kernel_ms"] for k in ks]))
-        hjm = float(np.mean([k["host_jump_ms"] for k in ks]))
+        frame(0)
+        ctx.sync()
+        st1 = ctx.stats()
+        jms, hjm = st1["jitter_kernel_ms"], st1["host_jump_ms"]
+        # kernel time: the timed steps' own launches (HIP events on the kernel's stream)
+        kms = kernel_ms_timed if kernel_ms_timed else st1["render_kernel_ms"]
         frame(0, counters=True)
         ctx.sync()
         cs = ctx.stats()
-        bray = b_ray(cs["nodes_visited"], cs["tris_tested"], cs["rays_hit"], cs["rays"], spp)
-        achieved = rays_per_frame * bray / (kms * 1e-3) / 1e9
+        rays = cs["rays"]
+        bray = b_ray(cs["nodes_visited"], cs["tris_tested"], cs["rays_hit"], rays, spp)
+        # (1) SURVEY 8(d)'s figure: per-RAY algorithmic bytes (every ray charged 64 B per node it visits).  The
+        #     packet kernel fetches a node once per 64-ray WAVE through the scalar cache, so this is a model of
+        #     the reference's visit rule, not a bound on this kernel: its "fraction" exceeds 1.
+        hbm_alg = {"bytes_per_ray": bray, "bytes_per_launch": bray * rays_per_frame,
+                   "achieved_gbs": rays_per_frame * bray / (kms * 1e-3) / 1e9, "peak_gbs": HBM_PEAK_GBS,
+                   "frac": rays_per_frame * bray / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                   "note": "SURVEY 8(d) B_ray is per ray; the kernel fetches node/triangle records per 64-ray wave, "
+                           "so frac > 1 says the model is not a bound here, not that work was skipped"}
+        # (2) the same figure per WAVE: records the waves actually request (64 B per node, 128 B per camera-
+        #     relative triangle record) + the per-ray streams (jitter in, hit id out, colour, intensity)
+        wave_bytes = (cs["wave_node_fetches"] * 64.0 + cs["wave_tri_fetches"] * 128.0 +
+                      rays * (16.0 + (4.0 if want_ids else 0.0) + 8.0 / spp) + cs["rays_hit"] * 24.0)
+        hbm_wave = {"bytes_per_launch": wave_bytes, "achieved_gbs": wave_bytes / (kms * 1e-3) / 1e9,
+                    "peak_gbs": HBM_PEAK_GBS, "frac": wave_bytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "node_records_per_ray": cs["wave_node_fetches"] / rays,
+                    "tri_records_per_ray": cs["wave_tri_fetches"] / rays,
+                    "note": "requested by the waves (scalar cache / L2 / MALL absorb most of it); an upper bound on "
+                            "what can reach HBM"}
+        # (3) what binds: fp64 VALU issue.  Instruction count from the committed PMC pass of THESE kernels
+        #     (source hash must match), time from this run.
         traffic = None
-        valu = None
+        lane_ops = None
+        pmc_note = None
         pmc_path = os.path.join(ROOT, "profiles", f"pmc_{args.workload}.json")
         if os.path.exists(pmc_path):
             try:
                 pmc = json.load(open(pmc_path))
-                traffic = pmc.get("hbm_bytes_per_launch")
-                # the bound that actually binds: non-fused fp64 VALU issue, 256 CU x 4 SIMD x
-                # 16 lanes x 2.4 GHz = 39.3 T lane-ops/s; instruction count from the committed PMC pass
-                vi = pmc.get(pmc.get("dominant_kernel", ""), {}).get("SQ_INSTS_VALU")
-                if vi:
-                    valu = {"lane_ops_per_launch": vi * 64, "peak_lane_ops_per_s": 39.3e12,
-                            "frac_of_fp64_issue_peak": vi * 64 / (kms * 1e-3) / 39.3e12,
-                            "source": "profiles/pmc_%s.json (SQ_INSTS_VALU x 64)" % args.workload}
-            except Exception:
-                traffic = None
-        # host hand-over cost (PCIe), never part of `value`
+                if pmc.get("kernel_source_hash") != kernel_source_hash():
+                    pmc_note = (f"profiles/pmc_{args.workload}.json was collected on other kernel sources "
+                                f"({pmc.get('kernel_source_hash')} != {kernel_source_hash()}): re-run profiles/run_prof.sh")
+                    print("bench.py: WARNING: " + pmc_note, file=sys.stderr)
+                elif pmc.get("spp") not in (None, spp) or pmc.get("image") not in (None, [H, W]):
+                    pmc_note = f"profiles/pmc_{args.workload}.json is for another frame shape"
+                else:
+                    traffic = pmc.get("hbm_bytes_per_launch")
+                    vi = pmc.get(pmc.get("dominant_kernel", ""), {}).get("SQ_INSTS_VALU")
+                    lane_ops = vi * 64 if vi else None
+                    pmc_note = f"profiles/pmc_{args.workload}.json (SQ_INSTS_VALU x 64; FETCH_SIZE/WRITE_SIZE passes)"
+            except Exception as e:
+                pmc_note = f"profiles/pmc_{args.workload}.json unreadable: {e}"
+        else:
+            pmc_note = f"no profiles/pmc_{args.workload}.json: run profiles/run_prof.sh <tag> {args.workload}"
+        achieved = lane_ops / (kms * 1e-3) / 1e12 if lane_ops else None
+        roofline = {"bound": "fp64_valu_issue", "achieved": achieved, "peak": FP64_LANE_OPS_PEAK / 1e12,
+                    "unit": "T lane-ops/s", "frac": achieved / (FP64_LANE_OPS_PEAK / 1e12) if achieved else None,
+                    "traffic": traffic,
+                    "kernel": "rtk::render_packet_kernel", "kernel_ms": kms,
+                    "kernel_ms_source": ("HIP events of the %d timed launches" % args.steps) if kernel_ms_timed
+                    else "HIP events of one launch after the timed loop",
+                    "lane_ops_per_launch": lane_ops, "counters_from": pmc_note,
+                    "peak_note": "256 CU x 4 SIMD x 16 lanes x 2.4 GHz, no fma (-ffp-contract=off is the parity contract)",
+                    "rays_per_launch": rays_per_frame, "kernel_only_mrays_s": rays_per_frame / (kms * 1e-3) / 1e6,
+                    "nodes_per_ray": cs["nodes_visited"] / rays, "tris_per_ray": cs["tris_tested"] / rays,
+                    "hit_rate": cs["rays_hit"] / rays,
+                    "hbm_measured_frac": traffic / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic else None,
+                    "hbm_algorithmic": hbm_alg, "hbm_per_wave": hbm_wave}
+        # host hand-over cost (PCIe, page-locked host buffers), never part of `value`
         frame(0)
         ctx.sync()
         t1 = time.perf_counter()
@@ -373,50 +480,104 @@ def main():
             t1 = time.perf_counter()
             ctx.download(intensity=False, rgb=False, hit_ids=True)
             dl_ids_ms = (time.perf_counter() - t1) * 1e3
+        # SURVEY 8(d)'s wall metric for this config: per frame, host BVH build + upload + render + read-back
+        end_to_end = None
+        if not args.lean:
+            try:
+                e2e = []
+                for i in range(3):
+                    t1 = time.perf_counter()
+                    h2 = ra.HostScene(coords, colors, 0)
+                    ctx.upload(h2)
+                    ctx.rng_seek(0)
+                    ctx.render(*cam, H, W, spp, hit_ids=want_ids)
+                    ctx.download(hit_ids=False)
+                    t2 = time.perf_counter()
+                    if want_ids:
+                        ctx.download(intensity=False, rgb=False, hit_ids=True)
+                    t3 = time.perf_counter()
+                    h2.close()
+                    e2e.append((t2 - t1, t3 - t1))
+                fr = float(np.mean([x[0] for x in e2e[1:]]))
+                fi = float(np.mean([x[1] for x in e2e[1:]]))
+                end_to_end = {"ms_per_frame": fr * 1e3, "mrays_per_s": rays_per_frame / fr / 1e6,
+                              "ms_per_frame_with_hit_ids": fi * 1e3 if want_ids else None,
+                              "mrays_per_s_with_hit_ids": rays_per_frame / fi / 1e6 if want_ids else None,
+                              "includes": "host BVH build (rt_scene_build, %d threads) + upload + sampler + render + "
+                                          "read-back of intensity and rgb into page-locked host memory; serial, "
+                                          "nothing overlapped" % int(ra.lib.rt_host_threads())}
+            except Exception as e:
+                end_to_end = {"error": str(e)}
+        # the whole driver on big frames: 4096^2 x 64 spp, 8 meshes rebuilt per timestep, 2 cameras, P6 files
+        soak = None
+        if not args.lean and not args.no_multiframe and world == 1 and H * W >= 4096 * 4096:
+            try:
+                import tempfile
+                sys.path.insert(0, os.path.join(ROOT, "profiles", "tools"))
+                import soak_driver
+                d = tempfile.mkdtemp(prefix="rtbench_soak_")
+                soak_driver.run(2, 4096, d)  # warm-up
+                n_t = 8
+                el = soak_driver.run(n_t, 4096, d)
+                n_files = len(os.listdir(d))
+                for f in os.listdir(d):
+                    os.remove(os.path.join(d, f))
+                os.rmdir(d)
+                soak = {"frames_per_s": 2 * n_t / el, "frames": 2 * n_t, "seconds": el, "image": [4096, 4096], "spp": 64,
+                        "mrays_per_s": 2 * n_t * 4096 * 4096 * 64 / el / 1e6, "files_written": n_files,
+                        "includes": "per-timestep host BVH build (8 x 18,432 triangles, overlapped), upload, render, "
+                                    "read-back, 50 MB P6 file per frame"}
+            except Exception as e:
+                soak = {"error": str(e)}
         # fp32 FAST PATH (RT_FLAG_FP32), reported separately with its measured tolerance against the exact
         # f64 frame of the same samples -- never part of `value`
         fp32 = None
-        try:
-            frame(0)
-            exact = ctx.download(rgb=False, hit_ids=want_ids)
-            f32_ms = []
-            for _ in range(3):
-                frame(0, fp32=True)
-                ctx.sync()
-                f32_ms.append(ctx.stats()["render_kernel_ms"])
-            fast = ctx.download(rgb=False, hit_ids=want_ids)
-            d = np.abs(fast["intensity"] - exact["intensity"])
-            fp32 = {"kernel_ms": float(np.mean(f32_ms[1:])),
-                    "kernel_only_mrays_s": rays_per_frame / (float(np.mean(f32_ms[1:])) * 1e-3) / 1e6,
-                    "vs_f64_exact": {"max_abs_intensity_diff": float(d.max()), "mean_abs_intensity_diff": float(d.mean()),
-                                     "hit_id_mismatch_fraction":
-                                         float((fast["hit_prim"] != exact["hit_prim"]).mean()) if want_ids else None}}
-            del exact, fast, d
-        except Exception as e:  # the fast path must never take the bench line down
-            fp32 = {"error": str(e)}
-        # counter-based fast sampler (RT_SAMPLER_PHILOX): other samples than the reference, reported separately
         philox = None
-        try:
-            t_ph = []
-            for _ in range(3):
-                ctx.sync()
-                t1 = time.perf_counter()
-                frame(0, philox=True)
-                ctx.sync()
-                t_ph.append(time.perf_counter() - t1)
-            philox = {"ms_per_frame": float(np.mean(t_ph[1:])) * 1e3,
-                      "mrays_per_s": rays_per_frame / float(np.mean(t_ph[1:])) / 1e6,
-                      "note": "sampler kernel + traversal, no look-ahead needed; not the reference's samples"}
-        except Exception as e:
-            philox = {"error": str(e)}
+        if not args.lean:
+            try:
+                frame(0)
+                exact = ctx.download(rgb=False, hit_ids=want_ids)
+                f32_ms = []
+                for _ in range(3):
+                    frame(0, fp32=True)
+                    ctx.sync()
+                    f32_ms.append(ctx.stats()["render_kernel_ms"])
+                fast = ctx.download(rgb=False, hit_ids=want_ids)
+                d = np.abs(fast["intensity"] - exact["intensity"])
+                fp32 = {"kernel_ms": float(np.mean(f32_ms[1:])),
+                        "kernel_only_mrays_s": rays_per_frame / (float(np.mean(f32_ms[1:])) * 1e-3) / 1e6,
+                        "vs_f64_exact": {"max_abs_intensity_diff": float(d.max()), "mean_abs_intensity_diff": float(d.mean()),
+                                         "hit_id_mismatch_fraction":
+                                             float((fast["hit_prim"] != exact["hit_prim"]).mean()) if want_ids else None}}
+                del exact, fast, d
+            except Exception as e:  # the fast path must never take the bench line down
+                fp32 = {"error": str(e)}
+            # counter-based fast sampler (RT_SAMPLER_PHILOX): other samples than the reference, reported separately
+            try:
+                t_ph = []
+                for _ in range(3):
+                    ctx.sync()
+                    t1 = time.perf_counter()
+                    frame(0, philox=True)
+                    ctx.sync()
+                    t_ph.append(time.perf_counter() - t1)
+                philox = {"ms_per_frame": float(np.mean(t_ph[1:])) * 1e3,
+                          "mrays_per_s": rays_per_frame / float(np.mean(t_ph[1:])) / 1e6,
+                          "note": "sampler kernel + traversal, no look-ahead needed; not the reference's samples"}
+            except Exception as e:
+                philox = {"error": str(e)}
         cpu = None
         if args.cpu_rays > 0 and world == 1:  # the CPU baseline is timed on rank 0 at N = 1 only
             frame(0)
             got = ctx.download(rgb=False, hit_ids=want_ids)
-            if want_ids:
-                cpu = cpu_baseline(coords, colors, cam, H, W, spp, got, host, args.cpu_rays)
-            else:
-                cpu = cpu_baseline(coords, colors, cam, H, W, spp, None, host, args.cpu_rays)
+            cpu = cpu_baseline(coords, colors, cam, H, W, spp, got if want_ids else None, host, args.cpu_rays)
+            # the oracle is an allocation-free C restatement; the reference itself (Eigen dynamic temporaries,
+            # ~15 heap allocations per leaf visit) cannot be built on the GPU box.  SURVEY 6 [probed] timed it in
+            # the survey container: 0.2-0.4 Mrays/s on one core, i.e. roughly a tenth of this port.
+            cpu["reference_probed_mrays_s"] = [0.2, 0.4]
+            cpu["reference_vs_port_note"] = ("kind=port: plain-C restatement of the reference's algorithm; the compiled "
+                                             "reference measured 0.2-0.4 Mrays/s/core in the survey container "
+                                             "(SURVEY.md 6, [probed]) -- about 10x slower than this port")
         total_rays = rays_per_frame * args.steps * world
         value = total_rays / elapsed / 1e6
         out = {
@@ -436,20 +597,15 @@ def main():
                        "blas": int(host.info.n_meshes), "bvh_nodes": int(host.info.n_blas_nodes),
                        "sampler": "MT19937 reference stream (GPU GF(2) jump-ahead + jitter kernels, device-resident state)",
                        "hit_ids_written": want_ids, "frames_per_step_per_gpu": 1,
+                       "host_threads_per_rank": int(ra.lib.rt_host_threads()),
                        "parallelism": f"frame-sharded x{world}, no collective"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "rtk::render_packet_kernel", "kernel_ms": kms, "bytes_per_ray": bray,
-                         "rays_per_launch": rays_per_frame, "nodes_per_ray": cs["nodes_visited"] / cs["rays"],
-                         "tris_per_ray": cs["tris_tested"] / cs["rays"], "hit_rate": cs["rays_hit"] / cs["rays"],
-                         "kernel_only_mrays_s": rays_per_frame / (kms * 1e-3) / 1e6,
-                         "wave_node_fetches_per_ray": cs["wave_node_fetches"] / cs["rays"],
-                         "valu": valu},
+            "roofline": roofline,
             "cpu_baseline": cpu,
             "aux": {"jitter_kernel_ms": jms, "host_jump_ms_per_frame": hjm, "host_bvh_build_s": build_s,
                     "upload_s": upload_s, "stack_need": int(host.info.stack_need),
                     "download_frame_ms": dl_frame_ms, "download_hit_ids_ms": dl_ids_ms,
-                    "kernel_ms_timed_step": kernel_ms[-1] if kernel_ms else None,
+                    "jitter_kernel_ms_timed_step": jitter_ms_last,
+                    "end_to_end": end_to_end, "driver_4096x64": soak,
                     "multiframe": multiframe, "fp32_fast_path": fp32, "philox_sampler": philox, "single_frame_banded": banded},
         }
     if dist is not None:

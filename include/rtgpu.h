@@ -39,6 +39,11 @@ int rt_device_count(void);
  * 1..16.  OMP_NUM_THREADS is ignored on purpose (torchrun sets it to 1 for multi-rank jobs).  The reference
  * has one thread; no counterpart. */
 int rt_host_threads(void);
+/* Page-locked host memory for rt_download targets (hipHostMalloc): device-to-host copies into pageable memory
+ * run at ~10 GB/s, into pinned memory at the link's rate.  NULL on failure.  No counterpart in the reference
+ * (its frame never leaves the host). */
+void *rt_host_alloc(size_t bytes);
+void rt_host_free(void *p);
 
 /* ------------------------------------------------------------------ */
 /* Host BVH build + flatten.                                           */
@@ -171,6 +176,12 @@ typedef struct {
     uint64_t tris_tested;   /* RT_FLAG_COUNTERS */
     uint64_t rays_hit;      /* RT_FLAG_COUNTERS */
     uint64_t wave_node_fetches; /* RT_FLAG_COUNTERS: node records fetched per wave, summed (packet kernel) */
+    uint64_t wave_tri_fetches;  /* RT_FLAG_COUNTERS: triangle records fetched per wave, summed (packet kernel) */
+    /* running totals since rt_create over the launches whose events have been read (every rt_render reads its
+     * predecessor's; rt_last_stats reads the last one's): a loop of K rt_render calls followed by ONE
+     * rt_last_stats gives the K launches' kernel time without a sync per step */
+    double render_kernel_ms_total;
+    uint64_t render_launches_timed;
 } rt_stats;
 int rt_last_stats(const rt_ctx *ctx, rt_stats *out);
 int rt_sync(rt_ctx *ctx);

@@ -9,8 +9,8 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_${TAG}_${WL}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $REPO/bench.py --workload $WL --steps 5 --warmup 1 --cpu-rays 0 --no-multiframe"
-BENCH1="python3 $REPO/bench.py --workload $WL --steps 1 --warmup 0 --cpu-rays 0 --no-multiframe"
+BENCH="python3 $REPO/bench.py --workload $WL --steps 5 --warmup 1 --lean"
+BENCH1="python3 $REPO/bench.py --workload $WL --steps 1 --warmup 0 --lean"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/trace.log" 2>&1 || { echo "trace pass failed"; tail -5 "$OUT/trace.log"; exit 1; }
 echo "trace pass ok"
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- $BENCH1 > "$OUT/pmc_fetch.log" 2>&1 || { echo "fetch pass failed"; tail -5 "$OUT/pmc_fetch.log"; exit 1; }
@@ -29,4 +29,5 @@ timeout -s KILL 300 rocprofv3 --pmc SQ_INSTS_SMEM SQ_INST_CYCLES_SMEM SQ_INST_CY
 echo "sq3 pass ok"
 timeout -s KILL 300 rocprofv3 --pmc SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQC_TC_DATA_READ_REQ --output-format csv -d "$OUT/pmc_sqc" -- $BENCH1 > "$OUT/pmc_sqc.log" 2>&1 || { echo "sqc pass failed"; tail -5 "$OUT/pmc_sqc.log"; exit 0; }
 echo "sqc pass ok"
-find "$OUT" -name "*.csv" | head -40
+python3 $REPO/profiles/summarize_pmc.py "$OUT" "$OUT/pmc_${WL}.json" > "$OUT/summarize.log" 2>&1 && echo "summary ok: $OUT/pmc_${WL}.json"
+cp "$OUT"/trace/*/*kernel_stats.csv "$OUT/kernel_stats_${WL}.csv" 2>/dev/null || find "$OUT/trace" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats_${WL}.csv" \;

@@ -5,7 +5,11 @@ import collections
 import csv
 import glob
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from bench import kernel_source_hash  # noqa: E402  (the bench refuses summaries of other kernel sources)
 
 
 def main(src, dst):
@@ -49,6 +53,7 @@ def main(src, dst):
     dom = out.get(name, {})
     out["dominant_kernel"] = name
     out["hbm_bytes_per_launch"] = dom.get("hbm_bytes_per_launch")
+    out["kernel_source_hash"] = kernel_source_hash()
     json.dump(out, open(dst, "w"), indent=1)
     print(json.dumps(out, indent=1)[:3000])
 

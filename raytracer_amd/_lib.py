@@ -41,7 +41,8 @@ class RenderParams(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("render_kernel_ms", C.c_double), ("jitter_kernel_ms", C.c_double), ("host_jump_ms", C.c_double),
                 ("rays", C.c_uint64), ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64),
-                ("rays_hit", C.c_uint64), ("wave_node_fetches", C.c_uint64)]
+                ("rays_hit", C.c_uint64), ("wave_node_fetches", C.c_uint64), ("wave_tri_fetches", C.c_uint64),
+                ("render_kernel_ms_total", C.c_double), ("render_launches_timed", C.c_uint64)]
 
 
 # name -> (restype, argtypes).  Every symbol declared in include/rtgpu.h is listed here;
@@ -52,6 +53,8 @@ _PROTOS = {
     "rt_version": (C.c_char_p, []),
     "rt_device_count": (C.c_int, []),
     "rt_host_threads": (C.c_int, []),
+    "rt_host_alloc": (_VP, [C.c_size_t]),
+    "rt_host_free": (None, [_VP]),
     "rt_scene_build": (_VP, [C.c_int, C.POINTER(_VP), C.POINTER(_VP), _VP, C.c_int, C.c_int]),
     "rt_scene_free": (None, [_VP]),
     "rt_scene_info": (C.c_int, [_VP, C.POINTER(SceneInfo)]),

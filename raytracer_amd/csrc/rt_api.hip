@@ -171,6 +171,9 @@ struct rt_ctx {
     int32_t out_rows = 0, out_w = 0, out_spp = 0;
     uint32_t out_flags = 0;
     bool timing_pending = false, jitter_timed = false;
+    bool kernel_ms_known = false;       // stats.render_kernel_ms of the last launch has been read from its events
+    double kernel_ms_total = 0.0;       // over all launches since rt_create whose events were read
+    uint64_t kernel_launches_timed = 0;
     rt_stats stats{};
     // scratch for rt_trace_rays
     DevBuf<double> tr_o, tr_d, tr_t, tr_b, tr_c;
@@ -188,6 +191,19 @@ rtk::DevScene dev_scene(const rt_ctx* c) {
     d.tris = c->tris.p;
     d.colors = c->colors.p;
     return d;
+}
+
+// Kernel time of the last launch from its HIP events (the launch must have finished), once: kept in
+// stats.render_kernel_ms and added to the context's running total.
+int resolve_kernel_ms(rt_ctx* c) {
+    if (!c->timing_pending || c->kernel_ms_known) return RT_OK;
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+    c->stats.render_kernel_ms = ms;
+    c->kernel_ms_total += ms;
+    c->kernel_launches_timed += 1;
+    c->kernel_ms_known = true;
+    return RT_OK;
 }
 
 // Smallest LDS stack variant that holds the tree's need; 0 = global-memory stack.
@@ -496,6 +512,20 @@ const char* rt_last_error(void) { return g_err.c_str(); }
 const char* rt_version(void) { return "rtgpu 0.1 (gfx950, fp64 parity path)"; }
 
 int rt_host_threads(void) { return rt::host_threads(); }
+
+void* rt_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        g_err = std::string("rt_host_alloc: hipHostMalloc failed: ") + hipGetErrorString(e);
+        return nullptr;
+    }
+    return p;
+}
+
+void rt_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
+}
 
 int rt_device_count(void) {
     int n = 0;
@@ -902,7 +932,13 @@ int render_impl(rt_ctx* c, const rt_render_params* p, bool pipelined) {
     HIP_TRY(hipSetDevice(c->device));
     pipelined = pipelined && p->sampler == RT_SAMPLER_MT19937 && p->flags == 0;
     // outputs / jitter of the previous call may still be in flight
-    if (!pipelined) HIP_TRY(hipStreamSynchronize(c->stream));
+    if (!pipelined) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        // the previous launch is complete: its kernel time goes into the running total now, so that a loop of
+        // rt_render calls can be timed launch by launch without a stats call (and its sync) in between
+        int trc = resolve_kernel_ms(c);
+        if (trc) return trc;
+    }
     HIP_TRY(hipStreamSynchronize(c->rng_stream));
 
     int rc;
@@ -920,11 +956,13 @@ int render_impl(rt_ctx* c, const rt_render_params* p, bool pipelined) {
         if ((rc = c->hit_prim.ensure(n_smp))) return rc;
     if (p->flags & RT_FLAG_HIT_T)
         if ((rc = c->hit_t.ensure(n_smp))) return rc;
-    if ((rc = c->counters.ensure(4))) return rc;
+    if ((rc = c->counters.ensure(8))) return rc;
 
     c->stats = rt_stats{};
     c->stats.rays = n_smp;
     c->jitter_timed = false;
+    c->kernel_ms_known = false;
+    c->timing_pending = false;
 
     // ---- jitter ----
     int use = 0;
@@ -997,7 +1035,7 @@ int render_impl(rt_ctx* c, const rt_render_params* p, bool pipelined) {
     const int64_t n_tiles = int64_t(tiles_x) * tiles_y;
     if (n_tiles > 0x7fffffff) return fail(RT_E_LIMIT, "rt_render: too many tiles");
     const bool count = (p->flags & RT_FLAG_COUNTERS) != 0;
-    if (count) HIP_TRY(hipMemsetAsync(c->counters.p, 0, 4 * sizeof(unsigned long long), c->stream));
+    if (count) HIP_TRY(hipMemsetAsync(c->counters.p, 0, 8 * sizeof(unsigned long long), c->stream));
     if (p->flags & RT_FLAG_FP32) {
         // fp32 FAST PATH (not the parity path): same walk in binary32, see rt_kernels_fp32.hip.hpp
         if (c->stack_need > rtk::PACKET_STACK || c->n_nodes >= (size_t(1) << 26))
@@ -1206,8 +1244,8 @@ int rt_last_stats(const rt_ctx* cc, rt_stats* out) {
     if (c->timing_pending) {
         HIP_TRY(hipEventSynchronize(c->ev[1]));
         float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
-        c->stats.render_kernel_ms = ms;
+        int trc = resolve_kernel_ms(c);
+        if (trc) return trc;
         if (c->jitter_timed) {
             rt_ctx::JitterSlot& sl = c->slot[c->last_slot];
             HIP_TRY(hipEventSynchronize(sl.t1));
@@ -1215,8 +1253,9 @@ int rt_last_stats(const rt_ctx* cc, rt_stats* out) {
             c->stats.jitter_kernel_ms = ms;
         }
         if (c->out_flags & RT_FLAG_COUNTERS) {
-            unsigned long long h[4] = {0, 0, 0, 0};
+            unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             HIP_TRY(hipMemcpy(h, c->counters.p, sizeof(h), hipMemcpyDeviceToHost));
+            c->stats.wave_tri_fetches = h[4];
             c->stats.nodes_visited = h[0];
             c->stats.tris_tested = h[1];
             c->stats.rays_hit = h[2];
@@ -1224,6 +1263,8 @@ int rt_last_stats(const rt_ctx* cc, rt_stats* out) {
         }
         c->timing_pending = false;
     }
+    c->stats.render_kernel_ms_total = c->kernel_ms_total;
+    c->stats.render_launches_timed = c->kernel_launches_timed;
     *out = c->stats;
     return RT_OK;
 }

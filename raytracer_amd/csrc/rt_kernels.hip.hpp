@@ -559,6 +559,7 @@ __device__ __forceinline__ unsigned long long slab_rel(const SBox& b, const doub
 struct WaveCounters {
     unsigned long long nodes, tris;  // wave-uniform sums over participating lanes
     unsigned long long steps;        // node records fetched by the wave (the packet's own work)
+    unsigned long long tri_steps;    // triangle records fetched by the wave
 };
 
 template <bool FAST, int OCT, bool COUNT>
@@ -629,7 +630,10 @@ __device__ __forceinline__ void trace_packet(const PacketScene& sc, const unsign
                     first = ext[2 * e];
                     cnt = ext[2 * e + 1];
                 }
-                if (COUNT) wc.tris += (unsigned long long)cnt * (unsigned)__builtin_popcountll(inm);
+                if (COUNT) {
+                    wc.tris += (unsigned long long)cnt * (unsigned)__builtin_popcountll(inm);
+                    wc.tri_steps += cnt;
+                }
                 const bool in = __builtin_amdgcn_inverse_ballot_w64(inm);
                 for (uint32_t k = 0; k < cnt; ++k) {
                     // the whole 128-byte record in one round trip (both 64-byte lines requested together): staged
@@ -863,7 +867,7 @@ __global__ __launch_bounds__(NT, 8) void render_packet_kernel(const PacketArgs a
     wacc[1][lane] = 0.0;
     wacc[2][lane] = 0.0;
 
-    unsigned long long w_nodes = 0, w_tris = 0, w_steps = 0;  // lane 0 of each wave carries the wave's sums
+    unsigned long long w_nodes = 0, w_tris = 0, w_steps = 0, w_tsteps = 0;  // lane 0 of each wave carries the wave's sums
     uint32_t n_hits = 0;
 
     // The jitter pair of the NEXT batch is requested before this batch is traversed (one HBM round trip
@@ -977,7 +981,7 @@ __global__ __launch_bounds__(NT, 8) void render_packet_kernel(const PacketArgs a
         const bool risky = active && !(tame && a.fast_ok);
         const unsigned long long amask = __builtin_amdgcn_ballot_w64(active);
         if (amask != 0ull) {
-            WaveCounters wc = {0ull, 0ull, 0ull};
+            WaveCounters wc = {0ull, 0ull, 0ull, 0ull};
             // per axis: do all active lanes look the same way?  (inactive lanes are masked out of every result)
             const unsigned long long ngx = __builtin_amdgcn_ballot_w64(ix < 0.0) & amask;
             const unsigned long long ngy = __builtin_amdgcn_ballot_w64(iy < 0.0) & amask;
@@ -1010,6 +1014,7 @@ __global__ __launch_bounds__(NT, 8) void render_packet_kernel(const PacketArgs a
                 w_nodes += wc.nodes;
                 w_tris += wc.tris;
                 w_steps += wc.steps;
+                w_tsteps += wc.tri_steps;
             }
         }
         if (active) {
@@ -1134,6 +1139,7 @@ __global__ __launch_bounds__(NT, 8) void render_packet_kernel(const PacketArgs a
             atomicAdd(&a.counters[1], v1);
             atomicAdd(&a.counters[2], v2);
             atomicAdd(&a.counters[3], w_steps);
+            atomicAdd(&a.counters[4], w_tsteps);
         }
     }
 }

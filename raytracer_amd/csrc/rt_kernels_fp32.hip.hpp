@@ -403,7 +403,7 @@ __global__ __launch_bounds__(NT, 8) void render_packet32_kernel(const Packet32Ar
         h.prim = -1;
         const unsigned long long amask = __builtin_amdgcn_ballot_w64(active);
         if (amask != 0ull) {
-            rtk::WaveCounters wc = {0ull, 0ull, 0ull};
+            rtk::WaveCounters wc = {0ull, 0ull, 0ull, 0ull};
             const unsigned long long ngx = __builtin_amdgcn_ballot_w64(ix < 0.0f) & amask;
             const unsigned long long ngy = __builtin_amdgcn_ballot_w64(iy < 0.0f) & amask;
             const unsigned long long ngz = __builtin_amdgcn_ballot_w64(iz < 0.0f) & amask;
