@@ -285,30 +285,17 @@ def test_render_scene_driver_files_and_sharding(ctx, tmp_path):
     out = tmp_path / "all"
     out.mkdir()
     from raytracer_amd import _lib as L
-    # the driver uses a process-global context per device; start its stream at a known position
-    # by rendering relative to wherever it is: compare against an oracle stream discarded to that offset.
-    import ctypes as C
-    # render everything on "rank 0 of 1"
-    base_probe = tmp_path / "probe"
-    base_probe.mkdir()
+    # the driver's stream is process-global and never reseeded (rtmathutils.h:15-16): other tests of this
+    # process have advanced it, so the oracle starts where the driver stands now
+    base = int(L.lib.rt_driver_stream_position(0))
     ra.render_scene(H, W, sc, spp, out)
     names = sorted(os.listdir(out))
     assert names == [f"rtimage_{t}_cam{cam}.ppm" for t in range(3) for cam in range(2)]
-    # oracle: one continuous stream across (t, cam).  The global stream started at some multiple of the
-    # frame size only if this is the first driver call in the process; find the base from the first frame.
     frame_words = H * W * spp * 4
+    assert int(L.lib.rt_driver_stream_position(0)) == base + 6 * frame_words
     hdr = f"P6\n{W} {H}\n255\n".encode()
-    found_base = None
-    for base_frames in range(0, 64):
-        rng = orc.Rng()
-        rng.discard(base_frames * frame_words)
-        want = orc.Scene([c, c2], [k, k2], 0).render(*cams[0], H, W, spp, rng=rng, want_hits=False)
-        if (out / "rtimage_0_cam0.ppm").read_bytes() == hdr + want["rgb"].tobytes():
-            found_base = base_frames
-            break
-    assert found_base is not None, "first frame does not match the oracle at any frame-aligned stream offset"
     rng = orc.Rng()
-    rng.discard(found_base * frame_words)
+    rng.set_state(ra.mt19937_state_at(base))
     for t in range(3):
         osc = orc.Scene([c, c2], [k, k2], t)
         for ci, cam in enumerate(cams):
