@@ -160,6 +160,37 @@ typedef struct {
  * row bands seek to frame_base + row_begin*W*spp*4 themselves). */
 int rt_render(rt_ctx *ctx, const rt_render_params *params);
 
+/* ------------------------------------------------------------------ */
+/* rt_render for callers that CANNOT ALLOCATE.  No counterpart in the   */
+/* reference (which allocates per leaf visit); it exists for callers    */
+/* that must not reach hipMalloc: code under HIP graph capture, tight   */
+/* serving loops, harnesses that forbid allocation.                     */
+/* Same kernels and results as rt_render (packet path), but nothing is  */
+/* allocated or freed: the camera-relative node / TLAS / triangle       */
+/* records the prep kernels write and the visit counters live in a      */
+/* file-scope device array of RT_STATIC_SCRATCH_BYTES that every GPU    */
+/* the library runs on holds until the process ends; jitter and outputs */
+/* are the CALLER's device memory:                                      */
+/*   d_jitter   : (row_end-row_begin)*W*spp (ox,oy) pairs, order (j,i,k) */
+/*   d_intensity: rows*W f64     d_rgb: rows*W*3 u8                     */
+/*   d_hit_prim : rows*W*spp i32, required with RT_FLAG_HIT_IDS else NULL */
+/* params->sampler must be RT_SAMPLER_EXPLICIT (params->jitter is       */
+/* ignored); flags: RT_FLAG_HIT_IDS, RT_FLAG_COUNTERS.  The scene is    */
+/* the one last given to rt_upload_scene.  Limits (RT_E_LIMIT, with the */
+/* sizes in rt_last_error): 256 + 64*n_tlas + 64*n_dev_nodes +          */
+/* 128*n_tris bytes (each part rounded up to 256) must fit the array    */
+/* (about 400,000 triangles), and the tree must fit the packet kernel   */
+/* (stack_need <= 128).  The launch is asynchronous on the context's    */
+/* stream: rt_sync() before reading the outputs; rt_last_stats reports  */
+/* its kernel time and counters.  The MT19937 stream position and the   */
+/* outputs held for rt_download are untouched.  All calls on one GPU    */
+/* share that GPU's array: calls that overlap on one GPU (two contexts, */
+/* two threads) race -- serialise them.                                 */
+/* ------------------------------------------------------------------ */
+#define RT_STATIC_SCRATCH_BYTES (64u << 20)
+int rt_render_static(rt_ctx *ctx, const rt_render_params *params, const double *d_jitter, double *d_intensity,
+                     uint8_t *d_rgb, int32_t *d_hit_prim);
+
 /* Copy results of the last rt_render to host; any pointer may be NULL.
  *   intensity: rows*W  f64  gray/spp before quantisation (rtrender.cpp:61-62)
  *   rgb      : rows*W*3 u8  the P6 payload (rtrender.cpp:63-65)

@@ -19,6 +19,7 @@ RT_FLAG_HIT_IDS = 1
 RT_FLAG_COUNTERS = 2
 RT_FLAG_HIT_T = 4
 RT_FLAG_FP32 = 8
+RT_STATIC_SCRATCH_BYTES = 64 << 20
 
 
 class RtError(RuntimeError):
@@ -75,6 +76,7 @@ _PROTOS = {
     "rt_mt19937_state_at": (C.c_int, [C.c_uint32, C.c_uint64, _VP]),
     "rt_mt19937_stream_states": (C.c_int, [C.c_uint32, C.c_uint64, C.c_uint64, C.c_int, _VP]),
     "rt_render": (C.c_int, [_VP, C.POINTER(RenderParams)]),
+    "rt_render_static": (C.c_int, [_VP, C.POINTER(RenderParams), _VP, _VP, _VP, _VP]),
     "rt_download": (C.c_int, [_VP, _VP, _VP, _VP, _VP]),
     "rt_last_stats": (C.c_int, [_VP, C.POINTER(Stats)]),
     "rt_sync": (C.c_int, [_VP]),

@@ -184,6 +184,22 @@ class Context:
         self._shape = (p.row_end - p.row_begin, int(W), int(spp))
         self._flags = p.flags
 
+    def render_static(self, cam, p00, spacing, H, W, spp, d_jitter, d_intensity, d_rgb, d_hit_prim=None, *, rows=None,
+                      counters=False):
+        """rt_render_static: the packet render with NO allocation -- jitter and outputs are raw DEVICE addresses
+        (ints) of caller-owned memory, scratch is the library's file-scope device array.  Asynchronous: sync()
+        before reading the outputs."""
+        p = L.RenderParams()
+        p.camera_center[:] = list(L.f64(cam, 3))
+        p.pixel_00_center[:] = list(L.f64(p00, 3))
+        p.pixel_spacing[:] = list(L.f64(spacing, 6))
+        p.image_height, p.image_width, p.samples = int(H), int(W), int(spp)
+        p.row_begin, p.row_end = (0, int(H)) if rows is None else (int(rows[0]), int(rows[1]))
+        p.flags = (L.RT_FLAG_HIT_IDS if d_hit_prim else 0) | (L.RT_FLAG_COUNTERS if counters else 0)
+        p.sampler = L.RT_SAMPLER_EXPLICIT
+        L.check(lib.rt_render_static(self.h, C.byref(p), C.c_void_p(d_jitter), C.c_void_p(d_intensity), C.c_void_p(d_rgb),
+                                     C.c_void_p(d_hit_prim) if d_hit_prim else None), "rt_render_static")
+
     def download(self, intensity=True, rgb=True, hit_ids=None, hit_t=None, pinned=True):
         """Results of the last render as numpy arrays (in page-locked memory unless pinned=False)."""
         rows, W, spp = self._shape

@@ -27,6 +27,13 @@ struct rt_scene {
     std::unique_ptr<rt::Scene> s;
 };
 
+// Scratch of rt_render_static (the entry point that allocates nothing): the camera-relative node / TLAS /
+// triangle records the prep kernels write for the traversal kernel, and the visit counters.  One copy per GPU,
+// held until the process ends.  In host code this name is only a handle for hipGetSymbolAddress: the device
+// address is resolved once per device (static_scratch_ptr) and that pointer is what kernels, memsets and
+// copies get.
+static __device__ __align__(256) unsigned char scratch[RT_STATIC_SCRATCH_BYTES];
+
 namespace {
 
 thread_local std::string g_err;
@@ -167,6 +174,8 @@ struct rt_ctx {
     DevBuf<uint8_t> rgb;
     DevBuf<int32_t> hit_prim;
     DevBuf<unsigned long long> counters;
+    unsigned long long* stats_counters = nullptr;  // where the last launch's visit counters are (or null)
+    unsigned char* static_scratch = nullptr;       // this GPU's copy of the file-scope `scratch` (rt_render_static)
     DevBuf<uint32_t> gstack;
     int32_t out_rows = 0, out_w = 0, out_spp = 0;
     uint32_t out_flags = 0;
@@ -504,6 +513,26 @@ int ensure_staged_pool(rt_ctx* c, size_t n) {
 std::mutex g_global_mu;
 rt_ctx* g_global_ctx[64] = {};
 
+// Device address of `scratch` on each GPU (every GPU holds its own copy of the array at its own address).
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mu;
+unsigned char* g_scratch_ptr[kMaxDevices] = {};
+
+// Resolve (once per device, with that device current) the address of this device's copy of `scratch`.
+int static_scratch_ptr(int device, unsigned char** out) {
+    if (device < 0 || device >= kMaxDevices) return fail(RT_E_INVALID, "static scratch: device index out of range");
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (!g_scratch_ptr[device]) {
+        HIP_TRY(hipSetDevice(device));
+        void* ptr = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+        if (!ptr) return fail(RT_E_NO_DEVICE, "hipGetSymbolAddress(scratch) returned a null address");
+        g_scratch_ptr[device] = static_cast<unsigned char*>(ptr);
+    }
+    *out = g_scratch_ptr[device];
+    return RT_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -715,6 +744,8 @@ rt_ctx* rt_create(int device) {
         return nullptr;
     }
     if (c->d_state.ensure(rt::MT_N) != RT_OK) return nullptr;
+    // rt_render_static must not call anything that could allocate: its scratch address is resolved here
+    if (static_scratch_ptr(device, &c->static_scratch) != RT_OK) return nullptr;
     rt_ctx* raw = c.release();
     if (rt_rng_seed(raw, 5489u) != RT_OK) {
         rt_destroy(raw);
@@ -909,6 +940,102 @@ int rt_rng_state(rt_ctx* c, uint32_t* state624) {
 
 namespace {
 
+// Tile side (log2) of a traversal launch.  >= 256 rays per 8x8 tile from 4 spp on.
+// Small images (the reference's own 400x225 frames): one workgroup per 8x8 tile leaves most of the 2048
+// workgroup slots of the chip empty.  The packet kernels take any tile size, so halve the tile while there
+// are fewer than 8192 tiles and a wave (a quarter of the tile) still has >= 128 rays to walk.
+int pick_tile_log2(bool packet_like, int spp, int W, int rows) {
+    int tile_log2 = (spp >= 4) ? 3 : 4;
+    static const bool small_tiles = std::getenv("RT_NO_SMALL_TILES") == nullptr;
+    if (small_tiles && packet_like)
+        while (tile_log2 > 1 && int64_t((W + (1 << tile_log2) - 1) >> tile_log2) * ((rows + (1 << tile_log2) - 1) >> tile_log2) < 8192 &&
+               (int64_t(1) << (2 * (tile_log2 - 1) - 2)) * spp >= 128)
+            --tile_log2;
+    if (const char* e = std::getenv("RT_TILE_LOG2")) {  // tuning knob (packet kernels: 1..4, per-lane kernel: 3 or 4)
+        const int v = std::atoi(e);
+        if (v >= (packet_like ? 1 : 3) && v <= 4) tile_log2 = v;
+    }
+    return tile_log2;
+}
+
+// Device memory one packet launch touches besides the uploaded scene: the camera-relative records the prep
+// kernels write (scratch), the jitter pairs (input) and the outputs.  rt_render passes the context's own
+// buffers, rt_render_static a partition of the file-scope scratch array and the caller's pointers.
+struct PacketBuffers {
+    rt::DevNode* cam_nodes;
+    rt::DevNode* cam_tlas;
+    rtk::CamTri* cam_tris;
+    const double* jitter;
+    double* intensity;
+    uint8_t* rgb;
+    int32_t* hit_prim;
+    double* hit_t;
+    unsigned long long* counters;
+};
+
+// prep kernels + render_packet_kernel on c->stream, bracketed by the context's timing events.  Allocates nothing.
+int launch_packet(rt_ctx* c, const rt_render_params* p, int tile_log2, int tiles_x, int64_t n_tiles, const PacketBuffers& pb) {
+    const int W = p->image_width, spp = p->samples, rows = p->row_end - p->row_begin;
+    const bool count = pb.counters != nullptr;
+    const double ox = p->camera_center[0], oy = p->camera_center[1], oz = p->camera_center[2];
+    hipLaunchKernelGGL(rtk::prep_nodes_kernel, dim3((unsigned)((c->n_nodes + 255) / 256)), dim3(256), 0, c->stream,
+                       c->nodes.p, pb.cam_nodes, (long long)c->n_nodes, ox, oy, oz);
+    hipLaunchKernelGGL(rtk::prep_nodes_kernel, dim3((unsigned)((c->n_tlas + 255) / 256)), dim3(256), 0, c->stream,
+                       c->tlas.p, pb.cam_tlas, (long long)c->n_tlas, ox, oy, oz);
+    hipLaunchKernelGGL(rtk::prep_tris_kernel, dim3((unsigned)((c->n_tris + 255) / 256)), dim3(256), 0, c->stream,
+                       c->tris.p, pb.cam_tris, (long long)c->n_tris, ox, oy, oz);
+    HIP_TRY(hipGetLastError());
+    rtk::PacketArgs a;
+    a.sc.nodes = pb.cam_nodes;
+    a.sc.tlas = pb.cam_tlas;
+    a.sc.slot_root = c->slot_root.p;
+    a.sc.leaf_ext = c->leaf_ext.p;
+    a.sc.tris = pb.cam_tris;
+    a.sc.colors = c->colors.p;
+    for (int i = 0; i < 3; ++i) {
+        a.fpv.cam[i] = p->camera_center[i];
+        a.fpv.p00[i] = p->pixel_00_center[i];
+    }
+    for (int i = 0; i < 6; ++i) a.fpv.sp[i] = p->pixel_spacing[i];
+    a.W = W;
+    a.spp = spp;
+    a.row0 = p->row_begin;
+    a.rows = rows;
+    a.tile_log2 = tile_log2;
+    a.tiles_x = tiles_x;
+    a.n_tiles = (int32_t)n_tiles;
+    a.jitter = pb.jitter;
+    a.intensity = pb.intensity;
+    a.rgb = pb.rgb;
+    a.hit_prim = pb.hit_prim;
+    a.hit_t = pb.hit_t;
+    a.counters = pb.counters;
+    // finite coordinates => every node box (>= 1 triangle, rt_scene_build rejects empty meshes) has
+    // min <= max, and so has its camera-relative copy (subtraction rounds monotonically): level 2
+    a.pair64 = 0;  // 1 + log2(spp / 64) for spp = 64, 128, 256, ...: the one-pixel-per-batch instantiation
+    // (an even number of batches per wave: 16 or 4 pixels per wave, or one pixel of >= 128 samples)
+    if (spp >= 64 && (spp & (spp - 1)) == 0 && (tile_log2 == 3 || tile_log2 == 2 || (tile_log2 == 1 && spp >= 128)) &&
+        c->stack_need <= rtk::PAIR64_STACK &&
+        !std::getenv("RT_NO_PAIR64"))
+        for (int q = spp >> 6; q; q >>= 1) ++a.pair64;
+    a.interleave = std::getenv("RT_NO_INTERLEAVE") ? 0 : (a.pair64 ? 1 : 0);
+    if (const char* e = std::getenv("RT_INTERLEAVE")) a.interleave = std::atoi(e);  // experiment: 0, 1, 2, 4, ...
+    if (a.interleave && ((a.interleave & (a.interleave - 1)) || a.interleave > ((1 << (2 * tile_log2)) >> 2))) a.interleave = 0;
+    a.fast_ok = (c->max_abs_coord + std::fabs(ox) + std::fabs(oy) + std::fabs(oz)) < 1e100 ? 2 : 0;
+    HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+    if (count && a.pair64)
+        hipLaunchKernelGGL((rtk::render_packet_kernel<true, true>), dim3((unsigned)n_tiles), dim3(rtk::NT), 0, c->stream, a);
+    else if (count)
+        hipLaunchKernelGGL((rtk::render_packet_kernel<true, false>), dim3((unsigned)n_tiles), dim3(rtk::NT), 0, c->stream, a);
+    else if (a.pair64)
+        hipLaunchKernelGGL((rtk::render_packet_kernel<false, true>), dim3((unsigned)n_tiles), dim3(rtk::NT), 0, c->stream, a);
+    else
+        hipLaunchKernelGGL((rtk::render_packet_kernel<false, false>), dim3((unsigned)n_tiles), dim3(rtk::NT), 0, c->stream, a);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    return RT_OK;
+}
+
 // rt_render.  `pipelined` (rt_render_scene only, plain MT19937 frames without per-sample outputs): the
 // launch is enqueued behind the previous one instead of waiting for it, so the GPU goes from frame to
 // frame without a gap while the host reads the previous frame back.  Everything a launch touches is
@@ -1016,19 +1143,7 @@ int render_impl(rt_ctx* c, const rt_render_params* p, bool pipelined) {
     // ---- traversal ----
     // the packet kernels address nodes with a 32-bit scalar byte offset: node array < 4 GB (6.7e7 nodes)
     const bool packet = c->stack_need <= rtk::PACKET_STACK && !force_per_lane() && c->n_nodes < (size_t(1) << 26);
-    int tile_log2 = (spp >= 4) ? 3 : 4;  // >= 256 rays per 8x8 tile from 4 spp on
-    // Small images (the reference's own 400x225 frames): one workgroup per 8x8 tile leaves most of the 2048
-    // workgroup slots of the chip empty.  The packet kernels take any tile size, so halve the tile while there
-    // are fewer than 8192 tiles and a wave (a quarter of the tile) still has >= 128 rays to walk.
-    static const bool small_tiles = std::getenv("RT_NO_SMALL_TILES") == nullptr;
-    if (small_tiles && (packet || (p->flags & RT_FLAG_FP32)))
-        while (tile_log2 > 1 && int64_t((W + (1 << tile_log2) - 1) >> tile_log2) * ((rows + (1 << tile_log2) - 1) >> tile_log2) < 8192 &&
-               (int64_t(1) << (2 * (tile_log2 - 1) - 2)) * spp >= 128)
-            --tile_log2;
-    if (const char* e = std::getenv("RT_TILE_LOG2")) {  // tuning knob (packet kernels: 1..4, per-lane kernel: 3 or 4)
-        const int v = std::atoi(e);
-        if (v >= ((packet || (p->flags & RT_FLAG_FP32)) ? 1 : 3) && v <= 4) tile_log2 = v;
-    }
+    const int tile_log2 = pick_tile_log2(packet || (p->flags & RT_FLAG_FP32), spp, W, rows);
     const int ts = 1 << tile_log2;
     const int tiles_x = (W + ts - 1) / ts;
     const int tiles_y = (rows + ts - 1) / ts;
@@ -1036,6 +1151,7 @@ int render_impl(rt_ctx* c, const rt_render_params* p, bool pipelined) {
     if (n_tiles > 0x7fffffff) return fail(RT_E_LIMIT, "rt_render: too many tiles");
     const bool count = (p->flags & RT_FLAG_COUNTERS) != 0;
     if (count) HIP_TRY(hipMemsetAsync(c->counters.p, 0, 8 * sizeof(unsigned long long), c->stream));
+    c->stats_counters = count ? c->counters.p : nullptr;
     if (p->flags & RT_FLAG_FP32) {
         // fp32 FAST PATH (not the parity path): same walk in binary32, see rt_kernels_fp32.hip.hpp
         if (c->stack_need > rtk::PACKET_STACK || c->n_nodes >= (size_t(1) << 26))
@@ -1094,62 +1210,17 @@ int render_impl(rt_ctx* c, const rt_render_params* p, bool pipelined) {
         if ((rc = c->cam_nodes.ensure(c->n_nodes))) return rc;
         if ((rc = c->cam_tlas.ensure(c->n_tlas))) return rc;
         if ((rc = c->cam_tris.ensure((size_t)c->n_tris))) return rc;
-        const double ox = p->camera_center[0], oy = p->camera_center[1], oz = p->camera_center[2];
-        hipLaunchKernelGGL(rtk::prep_nodes_kernel, dim3((unsigned)((c->n_nodes + 255) / 256)), dim3(256), 0, c->stream,
-                           c->nodes.p, c->cam_nodes.p, (long long)c->n_nodes, ox, oy, oz);
-        hipLaunchKernelGGL(rtk::prep_nodes_kernel, dim3((unsigned)((c->n_tlas + 255) / 256)), dim3(256), 0, c->stream,
-                           c->tlas.p, c->cam_tlas.p, (long long)c->n_tlas, ox, oy, oz);
-        hipLaunchKernelGGL(rtk::prep_tris_kernel, dim3((unsigned)((c->n_tris + 255) / 256)), dim3(256), 0, c->stream,
-                           c->tris.p, c->cam_tris.p, (long long)c->n_tris, ox, oy, oz);
-        HIP_TRY(hipGetLastError());
-        rtk::PacketArgs a;
-        a.sc.nodes = c->cam_nodes.p;
-        a.sc.tlas = c->cam_tlas.p;
-        a.sc.slot_root = c->slot_root.p;
-        a.sc.leaf_ext = c->leaf_ext.p;
-        a.sc.tris = c->cam_tris.p;
-        a.sc.colors = c->colors.p;
-        for (int i = 0; i < 3; ++i) {
-            a.fpv.cam[i] = p->camera_center[i];
-            a.fpv.p00[i] = p->pixel_00_center[i];
-        }
-        for (int i = 0; i < 6; ++i) a.fpv.sp[i] = p->pixel_spacing[i];
-        a.W = W;
-        a.spp = spp;
-        a.row0 = p->row_begin;
-        a.rows = rows;
-        a.tile_log2 = tile_log2;
-        a.tiles_x = tiles_x;
-        a.n_tiles = (int32_t)n_tiles;
-        a.jitter = d_jitter;
-        a.intensity = c->intensity.p;
-        a.rgb = c->rgb.p;
-        a.hit_prim = (p->flags & RT_FLAG_HIT_IDS) ? c->hit_prim.p : nullptr;
-        a.hit_t = (p->flags & RT_FLAG_HIT_T) ? c->hit_t.p : nullptr;
-        a.counters = count ? c->counters.p : nullptr;
-        // finite coordinates => every node box (>= 1 triangle, rt_scene_build rejects empty meshes) has
-        // min <= max, and so has its camera-relative copy (subtraction rounds monotonically): level 2
-        a.pair64 = 0;  // 1 + log2(spp / 64) for spp = 64, 128, 256, ...: the one-pixel-per-batch instantiation
-        // (an even number of batches per wave: 16 or 4 pixels per wave, or one pixel of >= 128 samples)
-        if (spp >= 64 && (spp & (spp - 1)) == 0 && (tile_log2 == 3 || tile_log2 == 2 || (tile_log2 == 1 && spp >= 128)) &&
-            c->stack_need <= rtk::PAIR64_STACK &&
-            !std::getenv("RT_NO_PAIR64"))
-            for (int q = spp >> 6; q; q >>= 1) ++a.pair64;
-        a.interleave = std::getenv("RT_NO_INTERLEAVE") ? 0 : (a.pair64 ? 1 : 0);
-        if (const char* e = std::getenv("RT_INTERLEAVE")) a.interleave = std::atoi(e);  // experiment: 0, 1, 2, 4, ...
-        if (a.interleave && ((a.interleave & (a.interleave - 1)) || a.interleave > ((1 << (2 * tile_log2)) >> 2))) a.interleave = 0;
-        a.fast_ok = (c->max_abs_coord + std::fabs(ox) + std::fabs(oy) + std::fabs(oz)) < 1e100 ? 2 : 0;
-        HIP_TRY(hipEventRecord(c->ev[0], c->stream));
-        if (count && a.pair64)
-            hipLaunchKernelGGL((rtk::render_packet_kernel<true, true>), dim3((unsigned)n_tiles), dim3(rtk::NT), 0, c->stream, a);
-        else if (count)
-            hipLaunchKernelGGL((rtk::render_packet_kernel<true, false>), dim3((unsigned)n_tiles), dim3(rtk::NT), 0, c->stream, a);
-        else if (a.pair64)
-            hipLaunchKernelGGL((rtk::render_packet_kernel<false, true>), dim3((unsigned)n_tiles), dim3(rtk::NT), 0, c->stream, a);
-        else
-            hipLaunchKernelGGL((rtk::render_packet_kernel<false, false>), dim3((unsigned)n_tiles), dim3(rtk::NT), 0, c->stream, a);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+        PacketBuffers pb;
+        pb.cam_nodes = c->cam_nodes.p;
+        pb.cam_tlas = c->cam_tlas.p;
+        pb.cam_tris = c->cam_tris.p;
+        pb.jitter = d_jitter;
+        pb.intensity = c->intensity.p;
+        pb.rgb = c->rgb.p;
+        pb.hit_prim = (p->flags & RT_FLAG_HIT_IDS) ? c->hit_prim.p : nullptr;
+        pb.hit_t = (p->flags & RT_FLAG_HIT_T) ? c->hit_t.p : nullptr;
+        pb.counters = count ? c->counters.p : nullptr;
+        if ((rc = launch_packet(c, p, tile_log2, tiles_x, n_tiles, pb))) return rc;
     } else {
         // Per-lane traversal: trees deeper than the packet kernel's 64 pending bits, or forced.
         rtk::RenderArgs a;
@@ -1237,6 +1308,79 @@ extern "C" {
 
 int rt_render(rt_ctx* c, const rt_render_params* p) { return render_impl(c, p, false); }
 
+// rt_render for callers that cannot allocate: same prep + traversal kernels, the camera-relative records and
+// the counters in this GPU's copy of the file-scope `scratch`, jitter and outputs in the caller's device memory.
+// No hipMalloc / hipFree / DevBuf::ensure anywhere below.
+int rt_render_static(rt_ctx* c, const rt_render_params* p, const double* d_jitter, double* d_intensity, uint8_t* d_rgb,
+                     int32_t* d_hit_prim) {
+    if (!c || !p) return fail(RT_E_INVALID, "rt_render_static: null argument");
+    if (!d_jitter || !d_intensity || !d_rgb)
+        return fail(RT_E_INVALID, "rt_render_static: jitter, intensity and rgb device pointers are required");
+    if (!c->have_scene) return fail(RT_E_NO_SCENE, "rt_render_static: no scene uploaded");
+    const int H = p->image_height, W = p->image_width, spp = p->samples;
+    if (H < 1 || W < 1 || spp < 1) return fail(RT_E_INVALID, "rt_render_static: image size and samples must be >= 1");
+    if (p->row_begin < 0 || p->row_end > H || p->row_begin >= p->row_end)
+        return fail(RT_E_INVALID, "rt_render_static: bad row range");
+    if (p->sampler != RT_SAMPLER_EXPLICIT)
+        return fail(RT_E_INVALID, "rt_render_static: only RT_SAMPLER_EXPLICIT (caller-supplied device jitter); the "
+                                  "MT19937 sampler keeps per-launch jitter and stream-state buffers");
+    if (p->flags & ~(RT_FLAG_HIT_IDS | RT_FLAG_COUNTERS))
+        return fail(RT_E_INVALID, "rt_render_static: only RT_FLAG_HIT_IDS and RT_FLAG_COUNTERS are supported");
+    if ((p->flags & RT_FLAG_HIT_IDS) && !d_hit_prim)
+        return fail(RT_E_INVALID, "rt_render_static: RT_FLAG_HIT_IDS needs a hit-id device pointer");
+    if ((int64_t)spp * 256 > (int64_t)1 << 30) return fail(RT_E_LIMIT, "rt_render_static: samples per pixel too large");
+    if (c->stack_need > rtk::PACKET_STACK || c->n_nodes >= (size_t(1) << 26))
+        return fail(RT_E_LIMIT, "rt_render_static: the tree needs the per-lane kernel (traversal stack > 128 entries)");
+    // partition of the scratch array: [counters 256 B][cam_tlas][cam_nodes][cam_tris], each 256-byte aligned
+    auto up256 = [](size_t v) { return (v + 255) & ~size_t(255); };
+    const size_t off_tlas = 256;
+    const size_t off_nodes = off_tlas + up256(c->n_tlas * sizeof(rt::DevNode));
+    const size_t off_tris = off_nodes + up256(c->n_nodes * sizeof(rt::DevNode));
+    const size_t need = off_tris + up256(size_t(c->n_tris) * sizeof(rtk::CamTri));
+    if (need > size_t(RT_STATIC_SCRATCH_BYTES))
+        return fail(RT_E_LIMIT, "rt_render_static: scene needs " + std::to_string(need) + " bytes of scratch (" +
+                                    std::to_string(c->n_tris) + " triangles, " + std::to_string(c->n_nodes) +
+                                    " nodes), the static array holds " + std::to_string(size_t(RT_STATIC_SCRATCH_BYTES)) +
+                                    "; use rt_render");
+    unsigned char* const ptr = c->static_scratch;  // resolved in rt_create with hipGetSymbolAddress
+    if (!ptr) return fail(RT_E_NO_DEVICE, "rt_render_static: scratch address not resolved");
+    const int rows = p->row_end - p->row_begin;
+    HIP_TRY(hipSetDevice(c->device));
+    // the previous launch of this context may still be reading the scratch records
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    int rc = resolve_kernel_ms(c);
+    if (rc) return rc;
+    c->stats = rt_stats{};
+    c->stats.rays = uint64_t(rows) * uint64_t(W) * uint64_t(spp);
+    c->jitter_timed = false;
+    c->kernel_ms_known = false;
+    c->timing_pending = false;
+    const int tile_log2 = pick_tile_log2(true, spp, W, rows);
+    const int ts = 1 << tile_log2;
+    const int tiles_x = (W + ts - 1) / ts;
+    const int64_t n_tiles = int64_t(tiles_x) * ((rows + ts - 1) / ts);
+    if (n_tiles > 0x7fffffff) return fail(RT_E_LIMIT, "rt_render_static: too many tiles");
+    const bool count = (p->flags & RT_FLAG_COUNTERS) != 0;
+    // the array keeps the last call's contents: the counters must start at zero
+    if (count) HIP_TRY(hipMemsetAsync(ptr, 0, 8 * sizeof(unsigned long long), c->stream));
+    c->stats_counters = count ? reinterpret_cast<unsigned long long*>(ptr) : nullptr;
+    PacketBuffers pb;
+    pb.cam_tlas = reinterpret_cast<rt::DevNode*>(ptr + off_tlas);
+    pb.cam_nodes = reinterpret_cast<rt::DevNode*>(ptr + off_nodes);
+    pb.cam_tris = reinterpret_cast<rtk::CamTri*>(ptr + off_tris);
+    pb.jitter = d_jitter;
+    pb.intensity = d_intensity;
+    pb.rgb = d_rgb;
+    pb.hit_prim = (p->flags & RT_FLAG_HIT_IDS) ? d_hit_prim : nullptr;
+    pb.hit_t = nullptr;
+    pb.counters = count ? reinterpret_cast<unsigned long long*>(ptr) : nullptr;
+    if ((rc = launch_packet(c, p, tile_log2, tiles_x, n_tiles, pb))) return rc;
+    HIP_TRY(hipEventRecord(c->front_last_use, c->stream));  // rt_upload_scene waits for it before reusing the set
+    c->front_used = true;
+    c->timing_pending = true;
+    return RT_OK;
+}
+
 int rt_last_stats(const rt_ctx* cc, rt_stats* out) {
     if (!cc || !out) return fail(RT_E_INVALID, "rt_last_stats: null argument");
     rt_ctx* c = const_cast<rt_ctx*>(cc);
@@ -1252,9 +1396,9 @@ int rt_last_stats(const rt_ctx* cc, rt_stats* out) {
             HIP_TRY(hipEventElapsedTime(&ms, sl.t0, sl.t1));
             c->stats.jitter_kernel_ms = ms;
         }
-        if (c->out_flags & RT_FLAG_COUNTERS) {
+        if (c->stats_counters) {
             unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            HIP_TRY(hipMemcpy(h, c->counters.p, sizeof(h), hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(h, c->stats_counters, sizeof(h), hipMemcpyDeviceToHost));
             c->stats.wave_tri_fetches = h[4];
             c->stats.nodes_visited = h[0];
             c->stats.tris_tested = h[1];
