@@ -217,6 +217,21 @@ typedef struct {
 int rt_last_stats(const rt_ctx *ctx, rt_stats *out);
 int rt_sync(rt_ctx *ctx);
 
+/* Test seam: the tile cuts of the last rt_render (packet path; DESIGN.md 4.2 "tile cuts"): per pixel tile 32
+ * words -- header (bit31 valid, bits 10..8 octant, bits 7..0 entry count) and up to 31 traversal descriptors in
+ * visit order at which the walk of that tile's rays starts instead of at the TLAS root.  Returns the number of
+ * tiles (0 when the last render made no cuts), or a negative error; tiles are numbered row-major, tiles_x per
+ * row, (1 << tile_log2) pixels square.  No counterpart in the reference (its walk always starts at node 0,
+ * cpp/rtrayintersection.cpp:203). */
+int rt_last_cuts(rt_ctx *ctx, uint32_t *words, int64_t capacity_words, int32_t *tiles_x, int32_t *tile_log2);
+
+/* Host-only twin of the tile-cut kernel (the same code compiled for the host): the cuts rt_render would make
+ * for this scene, camera and image (only camera, sizes, samples and rows of `params` are read).  words = NULL
+ * returns the tile count.  Test seam: lets the CPU suite check the cuts' invariants and the GPU suite compare
+ * rt_last_cuts with it word for word. */
+int rt_tile_cuts_host(const rt_scene *scene, const rt_render_params *params, uint32_t *words, int64_t capacity_words,
+                      int32_t *tiles_x, int32_t *tile_log2);
+
 /* Raw device pointers of the last render's outputs (for callers that keep the
  * framebuffer on the GPU, e.g. a peer gather).  NULL if not produced. */
 int rt_device_outputs(rt_ctx *ctx, void **intensity, void **rgb, void **hit_prim);

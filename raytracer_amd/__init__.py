@@ -5,7 +5,7 @@ host-side mirror of the reference's Python interface (rtmain / rtscene / rtcamer
 Importing the package loads the shared library and fails loudly if it has not been built.
 """
 from ._lib import LIB_PATH, RtError, lib  # noqa: F401  (loads librtgpu.so or raises)
-from .api import Context, HostScene, mt19937_state_at, mt19937_stream_states, shard_frames, shard_rows, render_frame_banded, write_ppm  # noqa: F401
+from .api import Context, HostScene, tile_cuts_host, mt19937_state_at, mt19937_stream_states, shard_frames, shard_rows, render_frame_banded, write_ppm  # noqa: F401
 from .rtcamera import Camera  # noqa: F401
 from .rtscene import RenderType, Scene  # noqa: F401
 from .rtmain import render_scene  # noqa: F401

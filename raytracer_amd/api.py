@@ -118,6 +118,25 @@ class HostScene:
         return mesh, elem
 
 
+def tile_cuts_host(scene: HostScene, cam, p00, spacing, H, W, spp, rows=None):
+    """The tile cuts rt_render makes for this scene / camera / image, computed by the host twin of the cut kernel:
+    (words[n_tiles, 32] uint32, tiles_x, tile_log2)."""
+    p = L.RenderParams()
+    p.camera_center[:] = list(L.f64(cam, 3))
+    p.pixel_00_center[:] = list(L.f64(p00, 3))
+    p.pixel_spacing[:] = list(L.f64(spacing, 6))
+    p.image_height, p.image_width, p.samples = int(H), int(W), int(spp)
+    p.row_begin, p.row_end = (0, int(H)) if rows is None else (int(rows[0]), int(rows[1]))
+    tx, tl = C.c_int32(), C.c_int32()
+    n = lib.rt_tile_cuts_host(scene.h, C.byref(p), None, 0, C.byref(tx), C.byref(tl))
+    if n < 0:
+        raise L.RtError(lib.rt_last_error().decode())
+    words = np.zeros((n, 32), np.uint32)
+    L.check(min(0, lib.rt_tile_cuts_host(scene.h, C.byref(p), L.ptr(words), words.size, C.byref(tx), C.byref(tl))),
+            "rt_tile_cuts_host")
+    return words, tx.value, tl.value
+
+
 class Context:
     """One GPU.  Raises if no HIP device is usable: there is no CPU path."""
 
@@ -221,6 +240,17 @@ class Context:
         if d is not None:
             out["hit_t"] = d
         return out
+
+    def last_cuts(self):
+        """Tile cuts of the last render: (words[n_tiles, 32] uint32, tiles_x, tile_log2); n_tiles = 0 if none were made."""
+        tx, tl = C.c_int32(), C.c_int32()
+        n = lib.rt_last_cuts(self.h, None, 0, C.byref(tx), C.byref(tl))
+        if n < 0:
+            raise L.RtError(lib.rt_last_error().decode())
+        words = np.zeros((n, 32), np.uint32)
+        if n:
+            L.check(min(0, lib.rt_last_cuts(self.h, L.ptr(words), words.size, C.byref(tx), C.byref(tl))), "rt_last_cuts")
+        return words, tx.value, tl.value
 
     def stats(self):
         s = L.Stats()

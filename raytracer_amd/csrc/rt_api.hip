@@ -120,6 +120,9 @@ struct rt_ctx {
     // camera-relative copies for the packet kernel (rebuilt per render by the prep kernels)
     DevBuf<rt::DevNode> cam_nodes, cam_tlas;
     DevBuf<rtk::CamTri> cam_tris;
+    DevBuf<uint32_t> cuts;  // per-tile entry lists of the last packet launch (tile_cut_kernel)
+    int64_t cut_tiles = 0;  // tiles of the last rt_render whose cuts are in `cuts` (0: no cuts were made)
+    int32_t cut_tiles_x = 0, cut_tile_log2 = 0;
     // fp32 fast path records (RT_FLAG_FP32), allocated on first use
     DevBuf<rtk32::Node32> nodes32;
     DevBuf<rtk32::Tlas32> tlas32;
@@ -768,6 +771,7 @@ void rt_destroy(rt_ctx* c) {
     c->cam_nodes.release();
     c->cam_tlas.release();
     c->cam_tris.release();
+    c->cuts.release();
     c->nodes32.release();
     c->tlas32.release();
     c->tris32.release();
@@ -971,6 +975,7 @@ struct PacketBuffers {
     int32_t* hit_prim;
     double* hit_t;
     unsigned long long* counters;
+    uint32_t* cuts;  // n_tiles * CUT_WORDS words for tile_cut_kernel, or null: every tile is walked from the root
 };
 
 // prep kernels + render_packet_kernel on c->stream, bracketed by the context's timing events.  Allocates nothing.
@@ -1022,6 +1027,28 @@ int launch_packet(rt_ctx* c, const rt_render_params* p, int tile_log2, int tiles
     if (const char* e = std::getenv("RT_INTERLEAVE")) a.interleave = std::atoi(e);  // experiment: 0, 1, 2, 4, ...
     if (a.interleave && ((a.interleave & (a.interleave - 1)) || a.interleave > ((1 << (2 * tile_log2)) >> 2))) a.interleave = 0;
     a.fast_ok = (c->max_abs_coord + std::fabs(ox) + std::fabs(oy) + std::fabs(oz)) < 1e100 ? 2 : 0;
+    // Tile cuts (tile_cut_kernel): the upper tree levels classified once per tile.  Not with visit counters (they
+    // count the reference's visit rule), not without the octant-specialised slab test the cut's argument rests on.
+    const bool no_cut = std::getenv("RT_NO_CUT") != nullptr;  // (comparison / test knob, read per launch)
+    a.cuts = nullptr;
+    if (pb.cuts && !count && a.fast_ok == 2 && !no_cut) {
+        rtk::CutArgs ca;
+        ca.nodes = pb.cam_nodes;
+        ca.tlas = pb.cam_tlas;
+        ca.slot_root = c->slot_root.p;
+        ca.fp = a.fpv;
+        ca.W = W;
+        ca.rows = rows;
+        ca.row0 = p->row_begin;
+        ca.tile_log2 = tile_log2;
+        ca.tiles_x = tiles_x;
+        ca.n_tiles = (int32_t)n_tiles;
+        ca.cuts = pb.cuts;
+        hipLaunchKernelGGL(rtk::tile_cut_kernel, dim3((unsigned)((n_tiles + rtk::CUT_THREADS - 1) / rtk::CUT_THREADS)),
+                           dim3(rtk::CUT_THREADS), 0, c->stream, ca);
+        HIP_TRY(hipGetLastError());
+        a.cuts = pb.cuts;
+    }
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     if (count && a.pair64)
         hipLaunchKernelGGL((rtk::render_packet_kernel<true, true>), dim3((unsigned)n_tiles), dim3(rtk::NT), 0, c->stream, a);
@@ -1220,7 +1247,12 @@ int render_impl(rt_ctx* c, const rt_render_params* p, bool pipelined) {
         pb.hit_prim = (p->flags & RT_FLAG_HIT_IDS) ? c->hit_prim.p : nullptr;
         pb.hit_t = (p->flags & RT_FLAG_HIT_T) ? c->hit_t.p : nullptr;
         pb.counters = count ? c->counters.p : nullptr;
+        if ((rc = c->cuts.ensure(size_t(n_tiles) * rtk::CUT_WORDS))) return rc;
+        pb.cuts = c->cuts.p;
         if ((rc = launch_packet(c, p, tile_log2, tiles_x, n_tiles, pb))) return rc;
+        c->cut_tiles = n_tiles;
+        c->cut_tiles_x = tiles_x;
+        c->cut_tile_log2 = tile_log2;
     } else {
         // Per-lane traversal: trees deeper than the packet kernel's 64 pending bits, or forced.
         rtk::RenderArgs a;
@@ -1336,7 +1368,8 @@ int rt_render_static(rt_ctx* c, const rt_render_params* p, const double* d_jitte
     const size_t off_tlas = 256;
     const size_t off_nodes = off_tlas + up256(c->n_tlas * sizeof(rt::DevNode));
     const size_t off_tris = off_nodes + up256(c->n_nodes * sizeof(rt::DevNode));
-    const size_t need = off_tris + up256(size_t(c->n_tris) * sizeof(rtk::CamTri));
+    const size_t off_cuts = off_tris + up256(size_t(c->n_tris) * sizeof(rtk::CamTri));
+    const size_t need = off_cuts;  // the records are required; the tile cuts are used when they fit behind them
     if (need > size_t(RT_STATIC_SCRATCH_BYTES))
         return fail(RT_E_LIMIT, "rt_render_static: scene needs " + std::to_string(need) + " bytes of scratch (" +
                                     std::to_string(c->n_tris) + " triangles, " + std::to_string(c->n_nodes) +
@@ -1374,6 +1407,10 @@ int rt_render_static(rt_ctx* c, const rt_render_params* p, const double* d_jitte
     pb.hit_prim = (p->flags & RT_FLAG_HIT_IDS) ? d_hit_prim : nullptr;
     pb.hit_t = nullptr;
     pb.counters = count ? reinterpret_cast<unsigned long long*>(ptr) : nullptr;
+    // tile cuts only speed the walk up (same results without): used when the image's tiles fit the array too
+    pb.cuts = (off_cuts + size_t(n_tiles) * rtk::CUT_WORDS * sizeof(uint32_t) <= size_t(RT_STATIC_SCRATCH_BYTES))
+                  ? reinterpret_cast<uint32_t*>(ptr + off_cuts)
+                  : nullptr;
     if ((rc = launch_packet(c, p, tile_log2, tiles_x, n_tiles, pb))) return rc;
     HIP_TRY(hipEventRecord(c->front_last_use, c->stream));  // rt_upload_scene waits for it before reusing the set
     c->front_used = true;
@@ -1431,6 +1468,69 @@ int rt_download(rt_ctx* c, double* intensity, uint8_t* rgb, int32_t* hit_prim, d
     if (hit_t) HIP_TRY(hipMemcpyAsync(hit_t, c->hit_t.p, n_smp * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return RT_OK;
+}
+
+int rt_tile_cuts_host(const rt_scene* scene, const rt_render_params* p, uint32_t* words, int64_t capacity_words,
+                      int32_t* tiles_x_out, int32_t* tile_log2_out) {
+    if (!scene || !p) return fail(RT_E_INVALID, "rt_tile_cuts_host: null argument");
+    const rt::Scene& s = *scene->s;
+    const int W = p->image_width, spp = p->samples, rows = p->row_end - p->row_begin;
+    if (W < 1 || spp < 1 || rows < 1) return fail(RT_E_INVALID, "rt_tile_cuts_host: bad image");
+    const int tile_log2 = pick_tile_log2(true, spp, W, rows);
+    const int ts = 1 << tile_log2;
+    const int tiles_x = (W + ts - 1) / ts;
+    const int64_t n_tiles = int64_t(tiles_x) * ((rows + ts - 1) / ts);
+    if (tiles_x_out) *tiles_x_out = tiles_x;
+    if (tile_log2_out) *tile_log2_out = tile_log2;
+    if (n_tiles > 0x7fffffff) return fail(RT_E_LIMIT, "rt_tile_cuts_host: too many tiles");
+    if (!words) return (int)n_tiles;
+    if (capacity_words < n_tiles * rtk::CUT_WORDS) return fail(RT_E_INVALID, "rt_tile_cuts_host: buffer too small");
+    // camera-relative boxes, as prep_nodes_kernel computes them
+    auto relative = [&](const rt::DevNode* in, size_t n) {
+        std::vector<rt::DevNode> out(in, in + n);
+        for (auto& v : out)
+            for (int k = 0; k < 3; ++k) {
+                v.mn[k] = v.mn[k] - p->camera_center[k];
+                v.mx[k] = v.mx[k] - p->camera_center[k];
+            }
+        return out;
+    };
+    const std::vector<rt::DevNode> nodes = relative(s.dev_nodes.data(), s.dev_nodes.size());
+    const std::vector<rt::DevNode> tlas = relative(s.dev_tlas.data(), s.dev_tlas.size());
+    rtk::CutArgs ca;
+    ca.nodes = nodes.data();
+    ca.tlas = tlas.data();
+    ca.slot_root = s.slot_root.data();
+    for (int i = 0; i < 3; ++i) {
+        ca.fp.cam[i] = p->camera_center[i];
+        ca.fp.p00[i] = p->pixel_00_center[i];
+    }
+    for (int i = 0; i < 6; ++i) ca.fp.sp[i] = p->pixel_spacing[i];
+    ca.W = W;
+    ca.rows = rows;
+    ca.row0 = p->row_begin;
+    ca.tile_log2 = tile_log2;
+    ca.tiles_x = tiles_x;
+    ca.n_tiles = (int32_t)n_tiles;
+    ca.cuts = words;
+    std::memset(words, 0, size_t(n_tiles) * rtk::CUT_WORDS * sizeof(uint32_t));
+    uint32_t lists[2 * (rtk::CUT_CAP + 1)];
+    for (int64_t t = 0; t < n_tiles; ++t) rtk::tile_cut_one(ca, (int)t, lists, 1);
+    return (int)n_tiles;
+}
+
+int rt_last_cuts(rt_ctx* c, uint32_t* words, int64_t capacity_words, int32_t* tiles_x, int32_t* tile_log2) {
+    if (!c) return fail(RT_E_INVALID, "rt_last_cuts: null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (tiles_x) *tiles_x = c->cut_tiles_x;
+    if (tile_log2) *tile_log2 = c->cut_tile_log2;
+    const int64_t n = c->cut_tiles * rtk::CUT_WORDS;
+    if (words && n > 0) {
+        if (capacity_words < n) return fail(RT_E_INVALID, "rt_last_cuts: buffer too small");
+        HIP_TRY(hipMemcpy(words, c->cuts.p, size_t(n) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    }
+    return (int)std::min<int64_t>(c->cut_tiles, 0x7fffffff);
 }
 
 int rt_device_outputs(rt_ctx* c, void** intensity, void** rgb, void** hit_prim) {

@@ -562,12 +562,24 @@ struct WaveCounters {
     unsigned long long tri_steps;    // triangle records fetched by the wave
 };
 
+// Entry list (tile cut, see tile_cut_kernel): n_entries < 0 -- walk from the TLAS root (the reference's own walk);
+// otherwise lane 1 + i of `vlist` holds entry i, a descriptor at which the walk (re)starts with every valid lane
+// taking part, in the reference's visit order.  The nodes above the entries are not tested: the cut guarantees
+// that every ray of the tile reaches exactly the same leaves, in the same order, either way.
 template <bool FAST, int OCT, bool COUNT>
 __device__ __forceinline__ void trace_packet(const PacketScene& sc, const unsigned long long valid_mask,
                                           const double dx, const double dy, const double dz, const double ix,
-                                          const double iy, const double iz, uint4* wstk, Hit& h, WaveCounters& wc) {
+                                          const double iy, const double iz, uint4* wstk, Hit& h, WaveCounters& wc,
+                                          const uint32_t vlist, int n_entries) {
     int sp = 0;
+    int ei = 1;
     uint32_t cur = rt::DESC_TLAS;
+    if (n_entries < 0) {
+        n_entries = 0;
+    } else {
+        if (n_entries == 0) return;
+        cur = (uint32_t)__builtin_amdgcn_readlane((int)vlist, 1);
+    }
     unsigned long long inm = valid_mask;
     for (;;) {
         // ---- descend through internal BLAS nodes (the hot loop) ----
@@ -725,7 +737,13 @@ __device__ __forceinline__ void trace_packet(const PacketScene& sc, const unsign
             }
         }
         // ---- pop ----
-        if (sp == 0) break;
+        if (sp == 0) {
+            if (ei >= n_entries) break;
+            ++ei;  // next entry of the tile's cut: every valid lane takes part again
+            cur = (uint32_t)__builtin_amdgcn_readlane((int)vlist, ei);
+            inm = valid_mask;
+            continue;
+        }
         --sp;
         const uint4 e = wstk[sp];
         cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.x);
@@ -760,6 +778,7 @@ struct PacketArgs {
     // cache (its 16 KB do not survive until the same wave's next pixel); 0: wave w owns the compact quadrant w
     int32_t interleave;
     int32_t fast_ok;  // host: >= 1: every |node coordinate - camera| < 1e100; 2: and every box has min <= max
+    const uint32_t* cuts;  // per tile CUT_WORDS words written by tile_cut_kernel (header + entries), or null
 };
 
 // blockIdx -> tile.  `tile` already gives XCD x (blocks b == x mod 8) a contiguous run of tiles.  When the
@@ -778,6 +797,247 @@ __device__ __forceinline__ void tile_coords(const int tile, const int n_tiles, c
         tix = ((blk % bpr) << 4) + (in & 15);
         tiy = xcd * (tiles_y >> 3) + ((blk / bpr) << 4) + (in >> 4);
     }
+}
+
+// =======================================================================================
+// Tile cuts.  All rays of an image start at the camera, and the rays of one pixel tile fill a narrow pyramid, so
+// most of the tree can be classified ONCE PER TILE instead of once per ray:
+//   * inside a BLAS a child's box lies inside its parent's (the builder takes unions, rtbvh.cpp:81-94, and the
+//     camera-relative subtraction and the slab products round monotonically), so in the octant-specialised slab
+//     test  tmin(parent) <= tmin(child)  and  tmax(child) <= tmax(parent)  hold exactly: a ray that passes a node's
+//     test passes the tests of all its BLAS ancestors.  The triangles a ray is tested against are therefore those
+//     of the leaves whose OWN box it passes -- internal BLAS tests only prune -- and any walk that reaches the same
+//     leaves in the same order returns the same hit, bit for bit;
+//   * TLAS nodes guard BLAS slots they need not contain (quirk 1, rtbvh.cpp:552-560), so their tests are kept
+//     unless the whole tile provably passes or fails them.
+// tile_cut_kernel (one thread per tile) walks the tree from the TLAS root and keeps a list of descriptors in
+// visit order.  A box is classified against the tile's four corner rays (offsets -0.5 / +0.5 of its outermost
+// pixels): with the signs of the direction components fixed over the tile, "near plane a <= far plane b" reads
+//     near_a * |d_b| <= far_b * |d_a|,   both sides affine in the sample position,
+// so it holds (fails) over the whole tile iff it does at the four corners; with a relative margin of 1e-5 at the
+// corners (the rounding of the per-ray test is ~1e-15, that of the sample position is bounded below) it is SURE.
+//   sure fail  -> the entry is dropped;   sure pass / internal -> replaced by its children;
+//   unsure leaf or TLAS node -> kept (it is tested per ray: an internal node is kept when a child is an unsure leaf).
+// The render kernel starts its walk at the list's entries (trace_packet) instead of the root: the ~15 upper
+// levels of slab tests per ray are done once per tile.  Any prefix of the refinement is a valid cut, so the list
+// simply stops growing at CUT_CAP entries.  Tiles whose rays do not share an octant, or graze an axis
+// (|d_a| < 1e-4 |d|), get no cut (header 0) and are walked from the root.
+// =======================================================================================
+constexpr int CUT_WORDS = 32;            // header + entries per tile (128 bytes)
+constexpr int CUT_CAP = CUT_WORDS - 1;   // entries
+constexpr uint32_t CUT_VALID = 0x80000000u;  // header: bit31 valid, bits 10..8 octant, bits 7..0 entry count
+constexpr int CUT_THREADS = 64;
+
+struct TileRays {
+    double D[4][3];  // |direction component| at the four corners (un-normalised: only ratios matter)
+    bool neg[3];     // component negative over the whole tile
+};
+
+// 0 = sure fail, 1 = sure pass, 2 = unsure.  mn/mx: camera-relative box.
+__host__ __device__ inline int cut_classify(const double* mn, const double* mx, const TileRays& tr) {
+    double nr[3], fr[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        nr[a] = tr.neg[a] ? -mx[a] : mn[a];
+        fr[a] = tr.neg[a] ? -mn[a] : mx[a];
+    }
+    if (!(fr[0] > 0.0 && fr[1] > 0.0 && fr[2] > 0.0)) return 0;  // tmax <= 0 for every ray of the tile
+    bool all_true = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            if (a == b) continue;
+            bool t_all = true, f_all = true;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const double A = nr[a] * tr.D[c][b], B = fr[b] * tr.D[c][a];  // B > 0
+                const double m = 1e-5 * (__builtin_fabs(A) + B);
+                t_all = t_all && (B - A >= m);
+                f_all = f_all && (A - B >= m);
+            }
+            if (f_all) return 0;
+            all_true = all_true && t_all;
+        }
+    }
+    return all_true ? 1 : 2;
+}
+
+struct CutArgs {
+    const rt::DevNode* nodes;  // camera-relative
+    const rt::DevNode* tlas;   // camera-relative
+    const int32_t* slot_root;
+    FrameParams fp;
+    int32_t W, rows, row0, tile_log2, tiles_x, n_tiles;
+    uint32_t* cuts;
+};
+
+// One tile's cut.  `lists`: two lists of CUT_CAP + 1 words, element (buffer, i) at lists[(buffer * (CUT_CAP + 1) + i) *
+// stride] (the kernel interleaves the threads of a workgroup in LDS; the host test seam passes stride 1).
+__host__ __device__ inline void tile_cut_one(const CutArgs& a, const int tile, uint32_t* const lists, const int stride) {
+#define RT_CUT_LIST(BUF, I) lists[((BUF) * (CUT_CAP + 1) + (I)) * stride]
+    const int ts = 1 << a.tile_log2;
+    const int tix = tile % a.tiles_x, tiy = tile / a.tiles_x;
+    uint32_t* const out = a.cuts + (size_t)tile * CUT_WORDS;
+
+    // the tile's corner rays: sample positions px + [-0.5, 0.5] (cpp/rtrender.cpp:53-56), a little padded
+    TileRays tr;
+    bool valid = true;
+    {
+        const double pad = 0.5 + 0x1p-20;
+        const double s0v[2] = {(double)(tix * ts) - pad, (double)(tix * ts + ts - 1) + pad};
+        const double s1v[2] = {(double)(tiy * ts + a.row0) - pad, (double)(tiy * ts + ts - 1 + a.row0) + pad};
+        double dd[4][3];
+        double mag = 0.0;  // bounds the magnitudes the per-ray sample position is computed from
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const double s0 = s0v[c & 1], s1 = s1v[c >> 1];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                dd[c][k] = ((a.fp.p00[k] + s0 * a.fp.sp[k]) + s1 * a.fp.sp[3 + k]) - a.fp.cam[k];
+                mag = __builtin_fmax(mag, __builtin_fabs(a.fp.p00[k]) + __builtin_fabs(s0 * a.fp.sp[k]) +
+                                              __builtin_fabs(s1 * a.fp.sp[3 + k]) + __builtin_fabs(a.fp.cam[k]));
+            }
+        }
+        double big = 0.0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) big = __builtin_fmax(big, __builtin_fabs(dd[c][k]));
+        // every component keeps its sign over the tile and stays well away from zero: relative to the direction
+        // (no grazing rays: |1/d| stays tame) and relative to the rounding of the sample position (2^-50 mag)
+        const double floor_abs = __builtin_fmax(1e-4 * big, 1e7 * 0x1p-50 * mag);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const bool ng = dd[0][k] < 0.0;
+            tr.neg[k] = ng;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const double v = ng ? -dd[c][k] : dd[c][k];
+                tr.D[c][k] = v;
+                valid = valid && (v >= floor_abs) && (v < 1e100);  // NaN / inf / sign change -> false
+            }
+        }
+        valid = valid && big > 0.0;
+    }
+    if (!valid) {
+        out[0] = 0u;
+        return;
+    }
+
+    // refinement rounds over a list in visit order; `fin` bit i: entry i cannot be refined further
+    int cur = 0, n = 1;
+    uint32_t fin = 0u;
+    RT_CUT_LIST(0, 0) = rt::DESC_TLAS;
+    for (int round = 0; round < 96; ++round) {
+        bool changed = false;
+        int m = 0;
+        uint32_t fin2 = 0u;
+        for (int i = 0; i < n; ++i) {
+            const uint32_t e = RT_CUT_LIST(cur, i);
+            const int rest = n - 1 - i;  // entries still to be copied / refined after this one
+            uint32_t r0 = 0u, r1 = 0u;  // replacement entries, in visit order
+            bool f0 = false, f1 = false;  // ... that cannot be refined further
+            int k = -1;  // number of replacement entries; -1: keep e as it is (final)
+            bool retry = false;  // keep e, but it may be refined in a later round (no room now)
+            if (!((fin >> i) & 1u)) {
+                if (e & rt::DESC_LEAF) {
+                    k = -1;
+                } else if (e & rt::DESC_TLAS) {
+                    const rt::DevNode nd = a.tlas[e & 0x3FFFFFFFu];
+                    const int cls = cut_classify(nd.mn, nd.mx, tr);
+                    if (cls == 0) {
+                        k = 0;
+                    } else if (cls == 1) {
+                        if (nd.left < 0) {
+                            if (nd.count >= 1 && nd.count <= 2) {  // the slots of a TLAS leaf, in visit order
+                                k = nd.count;
+                                r0 = rt::DESC_ROOT | (uint32_t)nd.first;
+                                r1 = rt::DESC_ROOT | (uint32_t)(nd.first + 1);
+                            }
+                        } else {
+                            k = 2;
+                            r0 = rt::DESC_TLAS | (uint32_t)nd.left;
+                            r1 = rt::DESC_TLAS | (uint32_t)(nd.left + 1);
+                        }
+                    }
+                } else if (e & rt::DESC_ROOT) {
+                    const rt::DevNode nd = a.nodes[a.slot_root[e & 0x1FFFFFFFu]];
+                    const int cls = cut_classify(nd.mn, nd.mx, tr);
+                    const bool leaf = (nd.desc & rt::DESC_LEAF) != 0u;
+                    if (cls == 0) {
+                        k = 0;
+                    } else if (cls == 1 || !leaf) {
+                        k = 1;  // the root's own test only prunes (BLAS monotonicity); a passing leaf root is final
+                        r0 = nd.desc;
+                        f0 = leaf;
+                    }
+                } else {
+                    // internal BLAS node: e = index of its left child, the right one is adjacent
+                    const rt::DevNode nl = a.nodes[e];
+                    const rt::DevNode nr = a.nodes[e + 1u];
+                    const int cl = cut_classify(nl.mn, nl.mx, tr);
+                    const int cr = cut_classify(nr.mn, nr.mx, tr);
+                    const bool ll = (nl.desc & rt::DESC_LEAF) != 0u, lr = (nr.desc & rt::DESC_LEAF) != 0u;
+                    // an unsure leaf is tested per ray, by its parent's step: then the parent stays
+                    if (!((cl == 2 && ll) || (cr == 2 && lr))) {
+                        k = 0;
+                        if (cl != 0) {
+                            r0 = nl.desc;
+                            f0 = ll;
+                            k = 1;
+                        }
+                        if (cr != 0) {
+                            if (k == 0) {
+                                r0 = nr.desc;
+                                f0 = lr;
+                            } else {
+                                r1 = nr.desc;
+                                f1 = lr;
+                            }
+                            ++k;
+                        }
+                    }
+                }
+                if (k >= 0 && m + k + rest > CUT_CAP) {
+                    k = -1;
+                    retry = true;
+                }
+            }
+            if (k < 0) {
+                RT_CUT_LIST(cur ^ 1, m) = e;
+                if (!retry) fin2 |= 1u << m;
+                ++m;
+            } else {
+                changed = true;
+                if (k >= 1) {
+                    RT_CUT_LIST(cur ^ 1, m) = r0;
+                    if (f0) fin2 |= 1u << m;
+                    ++m;
+                }
+                if (k >= 2) {
+                    RT_CUT_LIST(cur ^ 1, m) = r1;
+                    if (f1) fin2 |= 1u << m;
+                    ++m;
+                }
+            }
+        }
+        cur ^= 1;
+        n = m;
+        fin = fin2;
+        if (!changed) break;
+    }
+    const int oct = (tr.neg[0] ? 1 : 0) | (tr.neg[1] ? 2 : 0) | (tr.neg[2] ? 4 : 0);
+    out[0] = CUT_VALID | ((uint32_t)oct << 8) | (uint32_t)n;
+    for (int i = 0; i < n; ++i) out[1 + i] = RT_CUT_LIST(cur, i);
+#undef RT_CUT_LIST
+}
+
+__global__ __launch_bounds__(CUT_THREADS) void tile_cut_kernel(const CutArgs a) {
+    __shared__ uint32_t s_list[2 * (CUT_CAP + 1) * CUT_THREADS];  // [buffer][entry][thread]: conflict-free
+    const int tile = blockIdx.x * CUT_THREADS + threadIdx.x;
+    if (tile >= a.n_tiles) return;
+    tile_cut_one(a, tile, s_list + threadIdx.x, CUT_THREADS);
 }
 
 // ---- the compiler's fp64 division, for operands that need no scaling (see render_packet_kernel) ----
@@ -869,6 +1129,14 @@ __global__ __launch_bounds__(NT, 8) void render_packet_kernel(const PacketArgs a
 
     unsigned long long w_nodes = 0, w_tris = 0, w_steps = 0, w_tsteps = 0;  // lane 0 of each wave carries the wave's sums
     uint32_t n_hits = 0;
+
+    // the tile's cut (tile_cut_kernel): lane 0 = header, lanes 1.. = entries; one VGPR for the whole tile
+    uint32_t vcut = 0;
+    {
+        const uint32_t* const cuts = karg_ptr<const uint32_t, offsetof(PacketArgs, cuts)>();
+        if (cuts && lane < CUT_WORDS) vcut = cuts[(size_t)(tiy * a.tiles_x + tix) * CUT_WORDS + lane];
+    }
+    const uint32_t cut_hdr = (uint32_t)__builtin_amdgcn_readfirstlane((int)vcut);
 
     // The jitter pair of the NEXT batch is requested before this batch is traversed (one HBM round trip
     // off every batch's critical path: the kernel is bound by per-wave latency at 8 waves per SIMD).
@@ -989,13 +1257,20 @@ __global__ __launch_bounds__(NT, 8) void render_packet_kernel(const PacketArgs a
             const bool uni = (ngx == 0ull || ngx == amask) && (ngy == 0ull || ngy == amask) &&
                              (ngz == 0ull || ngz == amask) && a.fast_ok == 2;
             if (__builtin_amdgcn_ballot_w64(risky) != 0ull) {
-                trace_packet<false, -1, COUNT>(a.sc, amask, dx, dy, dz, ix, iy, iz, wstk, h, wc);
+                trace_packet<false, -1, COUNT>(a.sc, amask, dx, dy, dz, ix, iy, iz, wstk, h, wc, 0u, -1);
             } else if (uni) {
                 const int oct = (ngx != 0ull ? 1 : 0) | (ngy != 0ull ? 2 : 0) | (ngz != 0ull ? 4 : 0);
+                // The tile's cut holds for rays through the tile's pixels with offsets in [-0.5, 0.5] that all look
+                // into the octant it was computed for (caller-supplied offsets may be anything: checked here).
+                int n_ent = -1;
+                if ((cut_hdr & CUT_VALID) && (int)((cut_hdr >> 8) & 7u) == oct) {
+                    const bool in_range = __builtin_fabs(cs.jit.x) <= 0.5 && __builtin_fabs(cs.jit.y) <= 0.5;
+                    if ((__builtin_amdgcn_ballot_w64(!in_range) & amask) == 0ull) n_ent = (int)(cut_hdr & 0xffu);
+                }
                 switch (oct) {
-#define RT_OCT_CASE(O)                                                                          \
-    case O:                                                                                     \
-        trace_packet<true, O, COUNT>(a.sc, amask, dx, dy, dz, ix, iy, iz, wstk, h, wc);         \
+#define RT_OCT_CASE(O)                                                                                    \
+    case O:                                                                                               \
+        trace_packet<true, O, COUNT>(a.sc, amask, dx, dy, dz, ix, iy, iz, wstk, h, wc, vcut, n_ent);     \
         break;
                     RT_OCT_CASE(0)
                     RT_OCT_CASE(1)
@@ -1008,7 +1283,7 @@ __global__ __launch_bounds__(NT, 8) void render_packet_kernel(const PacketArgs a
 #undef RT_OCT_CASE
                 }
             } else {
-                trace_packet<true, -1, COUNT>(a.sc, amask, dx, dy, dz, ix, iy, iz, wstk, h, wc);
+                trace_packet<true, -1, COUNT>(a.sc, amask, dx, dy, dz, ix, iy, iz, wstk, h, wc, 0u, -1);
             }
             if (COUNT && lane == 0) {
                 w_nodes += wc.nodes;
