@@ -81,6 +81,9 @@ int rt_scene_tlas(const rt_scene *scene, double *boxes6, int32_t *blas_count, in
 /* slot = position in tlas.blases as the reference stores it (rtbvh.cpp:544-561) */
 int rt_scene_slot_info(const rt_scene *scene, int slot, int32_t *mesh, int32_t *n_nodes, int32_t *n_elems,
                        int64_t *tri_base);
+/* index of the slot's root in the device node array: node i of the slot (reference numbering) is record
+ * root + i, and an internal node's traversal descriptor is the record index of its left child */
+int64_t rt_scene_slot_dev_root(const rt_scene *scene, int slot);
 int rt_scene_slot_nodes(const rt_scene *scene, int slot, double *boxes6, int32_t *left, int64_t *count,
                         int32_t *min_idx);
 int rt_scene_slot_indices(const rt_scene *scene, int slot, int32_t *sorted_to_elem);
@@ -217,20 +220,20 @@ typedef struct {
 int rt_last_stats(const rt_ctx *ctx, rt_stats *out);
 int rt_sync(rt_ctx *ctx);
 
-/* Test seam: the tile cuts of the last rt_render (packet path; DESIGN.md 4.2 "tile cuts"): per pixel tile 32
- * words -- header (bit31 valid, bits 10..8 octant, bits 7..0 entry count) and up to 31 traversal descriptors in
- * visit order at which the walk of that tile's rays starts instead of at the TLAS root.  Returns the number of
- * tiles (0 when the last render made no cuts), or a negative error; tiles are numbered row-major, tiles_x per
- * row, (1 << tile_log2) pixels square.  No counterpart in the reference (its walk always starts at node 0,
- * cpp/rtrayintersection.cpp:203). */
-int rt_last_cuts(rt_ctx *ctx, uint32_t *words, int64_t capacity_words, int32_t *tiles_x, int32_t *tile_log2);
-
-/* Host-only twin of the tile-cut kernel (the same code compiled for the host): the cuts rt_render would make
- * for this scene, camera and image (only camera, sizes, samples and rows of `params` are read).  words = NULL
- * returns the tile count.  Test seam: lets the CPU suite check the cuts' invariants and the GPU suite compare
- * rt_last_cuts with it word for word. */
-int rt_tile_cuts_host(const rt_scene *scene, const rt_render_params *params, uint32_t *words, int64_t capacity_words,
-                      int32_t *tiles_x, int32_t *tile_log2);
+/* Test seams for the cuts (DESIGN.md 4.2 "cuts"; no counterpart in the reference, whose walk always starts at node
+ * 0, cpp/rtrayintersection.cpp:203).  Per block of (1 << level)^2 pixels 32 words: header (bit31 valid, bits 13..8
+ * the three axis kinds, bits 7..0 entry count) and up to 31 entries in visit order at which the walk of that
+ * block's rays starts instead of at the TLAS root.  Blocks are numbered row-major, *tiles_x per row; levels
+ * *level_lo .. *level_top exist (the top one is a single block).
+ * rt_last_cuts: those of the last rt_render, from the device.  Returns the number of blocks of `level` (0 when
+ * the last render made no cuts), or a negative error; words = NULL only queries.
+ * rt_tile_cuts_host: host-only twin (the same code compiled for the host) for this scene, camera and image (only
+ * camera, sizes, samples and rows of `params` are read): lets the CPU suite check the cuts against a brute-force
+ * walk and the GPU suite compare rt_last_cuts with it word for word. */
+int rt_last_cuts(rt_ctx *ctx, int level, uint32_t *words, int64_t capacity_words, int32_t *tiles_x, int32_t *level_lo,
+                 int32_t *level_top);
+int rt_tile_cuts_host(const rt_scene *scene, const rt_render_params *params, int level, uint32_t *words,
+                      int64_t capacity_words, int32_t *tiles_x, int32_t *level_lo, int32_t *level_top);
 
 /* Raw device pointers of the last render's outputs (for callers that keep the
  * framebuffer on the GPU, e.g. a peer gather).  NULL if not produced. */

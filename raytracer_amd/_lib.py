@@ -62,6 +62,7 @@ _PROTOS = {
     "rt_scene_tlas": (C.c_int, [_VP, _VP, _VP, _VP, _VP]),
     "rt_scene_slot_info": (C.c_int, [_VP, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                      C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
+    "rt_scene_slot_dev_root": (C.c_int64, [_VP, C.c_int]),
     "rt_scene_slot_nodes": (C.c_int, [_VP, C.c_int, _VP, _VP, _VP, _VP]),
     "rt_scene_slot_indices": (C.c_int, [_VP, C.c_int, _VP]),
     "rt_scene_prim_tables": (C.c_int, [_VP, _VP, _VP]),
@@ -80,9 +81,10 @@ _PROTOS = {
     "rt_download": (C.c_int, [_VP, _VP, _VP, _VP, _VP]),
     "rt_last_stats": (C.c_int, [_VP, C.POINTER(Stats)]),
     "rt_sync": (C.c_int, [_VP]),
-    "rt_last_cuts": (C.c_int, [_VP, _VP, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
-    "rt_tile_cuts_host": (C.c_int, [_VP, C.POINTER(RenderParams), _VP, C.c_int64, C.POINTER(C.c_int32),
-                                    C.POINTER(C.c_int32)]),
+    "rt_last_cuts": (C.c_int, [_VP, C.c_int, _VP, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                               C.POINTER(C.c_int32)]),
+    "rt_tile_cuts_host": (C.c_int, [_VP, C.POINTER(RenderParams), C.c_int, _VP, C.c_int64, C.POINTER(C.c_int32),
+                                    C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "rt_device_outputs": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(_VP)]),
     "rt_trace_rays": (C.c_int, [_VP, C.c_int64, _VP, _VP, _VP, _VP, _VP, _VP]),
     "rt_render_scene": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int, C.POINTER(_VP),

@@ -95,7 +95,7 @@ class HostScene:
         idx = np.empty(ne.value, np.int32)
         L.check(lib.rt_scene_slot_indices(self.h, s, L.ptr(idx)), "rt_scene_slot_indices")
         return dict(mesh=mesh.value, boxes=boxes, left=left, count=count, min_idx=min_idx, indices=idx,
-                    tri_base=tb.value)
+                    tri_base=tb.value, dev_root=int(lib.rt_scene_slot_dev_root(self.h, s)))
 
     def prim_tables(self):
         """prim id -> (mesh index, element index)."""
@@ -118,23 +118,25 @@ class HostScene:
         return mesh, elem
 
 
-def tile_cuts_host(scene: HostScene, cam, p00, spacing, H, W, spp, rows=None):
-    """The tile cuts rt_render makes for this scene / camera / image, computed by the host twin of the cut kernel:
-    (words[n_tiles, 32] uint32, tiles_x, tile_log2)."""
+def tile_cuts_host(scene: HostScene, cam, p00, spacing, H, W, spp, level=None, rows=None):
+    """The cuts rt_render makes for this scene / camera / image at `level` (blocks of 2^level pixels; default: the
+    finest level), computed by the host twin of the cut kernel: (words[n_blocks, 32] uint32, tiles_x, (lo, top))."""
     p = L.RenderParams()
     p.camera_center[:] = list(L.f64(cam, 3))
     p.pixel_00_center[:] = list(L.f64(p00, 3))
     p.pixel_spacing[:] = list(L.f64(spacing, 6))
     p.image_height, p.image_width, p.samples = int(H), int(W), int(spp)
     p.row_begin, p.row_end = (0, int(H)) if rows is None else (int(rows[0]), int(rows[1]))
-    tx, tl = C.c_int32(), C.c_int32()
-    n = lib.rt_tile_cuts_host(scene.h, C.byref(p), None, 0, C.byref(tx), C.byref(tl))
+    tx, lo, top = C.c_int32(), C.c_int32(), C.c_int32()
+    lib.rt_tile_cuts_host(scene.h, C.byref(p), -1, None, 0, None, C.byref(lo), C.byref(top))  # query the levels
+    level = lo.value if level is None else int(level)
+    n = lib.rt_tile_cuts_host(scene.h, C.byref(p), level, None, 0, C.byref(tx), None, None)
     if n < 0:
         raise L.RtError(lib.rt_last_error().decode())
     words = np.zeros((n, 32), np.uint32)
-    L.check(min(0, lib.rt_tile_cuts_host(scene.h, C.byref(p), L.ptr(words), words.size, C.byref(tx), C.byref(tl))),
+    L.check(min(0, lib.rt_tile_cuts_host(scene.h, C.byref(p), level, L.ptr(words), words.size, None, None, None)),
             "rt_tile_cuts_host")
-    return words, tx.value, tl.value
+    return words, tx.value, (lo.value, top.value)
 
 
 class Context:
@@ -241,16 +243,20 @@ class Context:
             out["hit_t"] = d
         return out
 
-    def last_cuts(self):
-        """Tile cuts of the last render: (words[n_tiles, 32] uint32, tiles_x, tile_log2); n_tiles = 0 if none were made."""
-        tx, tl = C.c_int32(), C.c_int32()
-        n = lib.rt_last_cuts(self.h, None, 0, C.byref(tx), C.byref(tl))
+    def last_cuts(self, level=None):
+        """Cuts of the last render at `level` (default: the finest): (words[n_blocks, 32] uint32, tiles_x, (lo, top));
+        n_blocks = 0 if the render made none."""
+        tx, lo, top = C.c_int32(), C.c_int32(), C.c_int32()
+        n = lib.rt_last_cuts(self.h, -1, None, 0, None, C.byref(lo), C.byref(top))  # query the levels
+        if n == 0:
+            return np.zeros((0, 32), np.uint32), 0, (0, 0)
+        level = lo.value if level is None else int(level)
+        n = lib.rt_last_cuts(self.h, level, None, 0, C.byref(tx), None, None)
         if n < 0:
             raise L.RtError(lib.rt_last_error().decode())
         words = np.zeros((n, 32), np.uint32)
-        if n:
-            L.check(min(0, lib.rt_last_cuts(self.h, L.ptr(words), words.size, C.byref(tx), C.byref(tl))), "rt_last_cuts")
-        return words, tx.value, tl.value
+        L.check(min(0, lib.rt_last_cuts(self.h, level, L.ptr(words), words.size, None, None, None)), "rt_last_cuts")
+        return words, tx.value, (lo.value, top.value)
 
     def stats(self):
         s = L.Stats()

@@ -78,6 +78,51 @@ struct DevBuf {
     }
 };
 
+// Levels of the cut hierarchy of one launch (cut_level_kernel): level l = blocks of (1 << l)^2 pixels, from the
+// single block of level `top` down to level `lo`, the finest one a 64-ray batch can ask for.
+struct CutPlan {
+    int lo = 0, top = 0;
+    int tiles_x[32] = {};
+    int64_t tiles[32] = {};
+    int64_t offset_words[32] = {};
+    int64_t total_words = 0;
+};
+
+// Entries a list of level l may hold: coarse levels only hand a starting point down (their blocks are refined
+// again, four times over, by their children), so they stop at half the room.
+int cut_cap(int l, const CutPlan& cp) {
+    static const int top_cap = std::getenv("RT_CUT_TOPCAP") ? std::atoi(std::getenv("RT_CUT_TOPCAP")) : 15;  // (tuning knob)
+    return (l > cp.lo + 1) ? std::max(1, std::min(top_cap, (int)rtk::CUT_CAP)) : (int)rtk::CUT_CAP;
+}
+
+CutPlan plan_cuts(int W, int rows, int spp, int tile_log2) {
+    CutPlan cp;
+    // a batch holds the rays of ceil(64 / spp) pixels or more: the smallest aligned block it can lie in
+    const int pix = (64 + spp - 1) / spp;
+    while ((1 << (2 * cp.lo)) < pix) ++cp.lo;
+    // ... but not below 2 x 2 pixels: measured on the 4096^2 x 64 spp frame, per-pixel cuts take 0.7 ms off the
+    // render kernel and cost 3 ms to make
+    cp.lo = std::max(cp.lo, 1);
+    if (const char* e = std::getenv("RT_CUT_LO")) cp.lo = std::max(0, std::atoi(e));  // (tuning knob)
+    cp.lo = std::min(cp.lo, tile_log2);
+    // The top level's blocks start at the TLAS root, one thread each: a long chain of dependent steps, but the
+    // same for any number of blocks, so the hierarchy starts where there are enough blocks to fill the GPU with
+    // that chain (8 x 8 pixels or the render tile), not at the single block that holds the image.
+    cp.top = std::max(tile_log2, 3);
+    if (const char* e = std::getenv("RT_CUT_TOP")) cp.top = std::max(cp.lo, std::atoi(e));  // (tuning knob)
+    int whole = 0;
+    while ((1 << whole) < std::max(W, rows)) ++whole;
+    cp.top = std::max(cp.lo, std::min(cp.top, std::max(whole, tile_log2)));
+    for (int l = cp.top; l >= cp.lo; --l) {
+        const int ts = 1 << l;
+        cp.tiles_x[l] = (W + ts - 1) / ts;
+        cp.tiles[l] = int64_t(cp.tiles_x[l]) * ((rows + ts - 1) / ts);
+        cp.offset_words[l] = cp.total_words;
+        cp.total_words += cp.tiles[l] * rtk::CUT_WORDS;
+    }
+    return cp;
+}
+
 }  // namespace
 
 struct rt_ctx {
@@ -121,8 +166,8 @@ struct rt_ctx {
     DevBuf<rt::DevNode> cam_nodes, cam_tlas;
     DevBuf<rtk::CamTri> cam_tris;
     DevBuf<uint32_t> cuts;  // per-tile entry lists of the last packet launch (tile_cut_kernel)
-    int64_t cut_tiles = 0;  // tiles of the last rt_render whose cuts are in `cuts` (0: no cuts were made)
-    int32_t cut_tiles_x = 0, cut_tile_log2 = 0;
+    CutPlan cut_plan;             // levels of the last rt_render's cuts in `cuts`
+    bool cut_plan_valid = false;  // false: the last render made none
     // fp32 fast path records (RT_FLAG_FP32), allocated on first use
     DevBuf<rtk32::Node32> nodes32;
     DevBuf<rtk32::Tlas32> tlas32;
@@ -626,6 +671,13 @@ int rt_scene_slot_info(const rt_scene* scene, int slot, int32_t* mesh, int32_t* 
     return RT_OK;
 }
 
+int64_t rt_scene_slot_dev_root(const rt_scene* scene, int slot) {
+    if (!scene) return fail(RT_E_INVALID, "rt_scene_slot_dev_root: null scene");
+    const rt::Scene& s = *scene->s;
+    if (slot < 0 || slot >= (int)s.slots.size()) return fail(RT_E_INVALID, "rt_scene_slot_dev_root: bad slot");
+    return s.slot_root[(size_t)slot];
+}
+
 int rt_scene_slot_nodes(const rt_scene* scene, int slot, double* boxes6, int32_t* left, int64_t* count,
                         int32_t* min_idx) {
     if (!scene) return fail(RT_E_INVALID, "rt_scene_slot_nodes: null scene");
@@ -975,7 +1027,7 @@ struct PacketBuffers {
     int32_t* hit_prim;
     double* hit_t;
     unsigned long long* counters;
-    uint32_t* cuts;  // n_tiles * CUT_WORDS words for tile_cut_kernel, or null: every tile is walked from the root
+    uint32_t* cuts;  // plan_cuts(...).total_words words for the cut levels, or null: every batch walks from the root
 };
 
 // prep kernels + render_packet_kernel on c->stream, bracketed by the context's timing events.  Allocates nothing.
@@ -1030,8 +1082,13 @@ int launch_packet(rt_ctx* c, const rt_render_params* p, int tile_log2, int tiles
     // Tile cuts (tile_cut_kernel): the upper tree levels classified once per tile.  Not with visit counters (they
     // count the reference's visit rule), not without the octant-specialised slab test the cut's argument rests on.
     const bool no_cut = std::getenv("RT_NO_CUT") != nullptr;  // (comparison / test knob, read per launch)
-    a.cuts = nullptr;
+    a.cut_lo = -1;
+    for (int l = 0; l < rtk::CUT_MAX_LEVELS; ++l) {
+        a.cut_lvl[l] = nullptr;
+        a.cut_tx[l] = 0;
+    }
     if (pb.cuts && !count && a.fast_ok == 2 && !no_cut) {
+        const CutPlan cp = plan_cuts(W, rows, spp, tile_log2);
         rtk::CutArgs ca;
         ca.nodes = pb.cam_nodes;
         ca.tlas = pb.cam_tlas;
@@ -1040,14 +1097,28 @@ int launch_packet(rt_ctx* c, const rt_render_params* p, int tile_log2, int tiles
         ca.W = W;
         ca.rows = rows;
         ca.row0 = p->row_begin;
-        ca.tile_log2 = tile_log2;
-        ca.tiles_x = tiles_x;
-        ca.n_tiles = (int32_t)n_tiles;
-        ca.cuts = pb.cuts;
-        hipLaunchKernelGGL(rtk::tile_cut_kernel, dim3((unsigned)((n_tiles + rtk::CUT_THREADS - 1) / rtk::CUT_THREADS)),
-                           dim3(rtk::CUT_THREADS), 0, c->stream, ca);
+        ca.parent = nullptr;
+        ca.parent_tiles_x = 0;
+        ca.mag = rtk::cut_magnitude(ca.fp, W, p->row_begin, rows);
+        for (int l = cp.top; l >= cp.lo; --l) {  // each level from its parent's cuts, the top one from the root
+            ca.lvl = l;
+            ca.cap = cut_cap(l, cp);
+            ca.tiles_x = cp.tiles_x[l];
+            ca.n_tiles = (int32_t)cp.tiles[l];
+            ca.cuts = pb.cuts + cp.offset_words[l];
+            const int64_t patches = int64_t((cp.tiles_x[l] + 7) / 8) * ((cp.tiles[l] / cp.tiles_x[l] + 7) / 8);
+            const int per_wg = rtk::CUT_THREADS / 64;  // one 8 x 8 patch of blocks per wave
+            hipLaunchKernelGGL(rtk::cut_level_kernel, dim3((unsigned)((patches + per_wg - 1) / per_wg)),
+                               dim3(rtk::CUT_THREADS), 0, c->stream, ca);
+            ca.parent = ca.cuts;
+            ca.parent_tiles_x = ca.tiles_x;
+            if (l < rtk::CUT_MAX_LEVELS) {
+                a.cut_lvl[l] = ca.cuts;
+                a.cut_tx[l] = ca.tiles_x;
+            }
+        }
         HIP_TRY(hipGetLastError());
-        a.cuts = pb.cuts;
+        a.cut_lo = cp.lo;
     }
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     if (count && a.pair64)
@@ -1247,12 +1318,13 @@ int render_impl(rt_ctx* c, const rt_render_params* p, bool pipelined) {
         pb.hit_prim = (p->flags & RT_FLAG_HIT_IDS) ? c->hit_prim.p : nullptr;
         pb.hit_t = (p->flags & RT_FLAG_HIT_T) ? c->hit_t.p : nullptr;
         pb.counters = count ? c->counters.p : nullptr;
-        if ((rc = c->cuts.ensure(size_t(n_tiles) * rtk::CUT_WORDS))) return rc;
+        const CutPlan cp = plan_cuts(W, rows, spp, tile_log2);
+        if (cp.tiles[cp.lo] > 0x7fffffff) return fail(RT_E_LIMIT, "rt_render: too many pixel blocks");
+        if ((rc = c->cuts.ensure(size_t(cp.total_words)))) return rc;
         pb.cuts = c->cuts.p;
         if ((rc = launch_packet(c, p, tile_log2, tiles_x, n_tiles, pb))) return rc;
-        c->cut_tiles = n_tiles;
-        c->cut_tiles_x = tiles_x;
-        c->cut_tile_log2 = tile_log2;
+        c->cut_plan = cp;
+        c->cut_plan_valid = !count;
     } else {
         // Per-lane traversal: trees deeper than the packet kernel's 64 pending bits, or forced.
         rtk::RenderArgs a;
@@ -1408,7 +1480,8 @@ int rt_render_static(rt_ctx* c, const rt_render_params* p, const double* d_jitte
     pb.hit_t = nullptr;
     pb.counters = count ? reinterpret_cast<unsigned long long*>(ptr) : nullptr;
     // tile cuts only speed the walk up (same results without): used when the image's tiles fit the array too
-    pb.cuts = (off_cuts + size_t(n_tiles) * rtk::CUT_WORDS * sizeof(uint32_t) <= size_t(RT_STATIC_SCRATCH_BYTES))
+    pb.cuts = (off_cuts + size_t(plan_cuts(W, rows, spp, tile_log2).total_words) * sizeof(uint32_t) <=
+               size_t(RT_STATIC_SCRATCH_BYTES))
                   ? reinterpret_cast<uint32_t*>(ptr + off_cuts)
                   : nullptr;
     if ((rc = launch_packet(c, p, tile_log2, tiles_x, n_tiles, pb))) return rc;
@@ -1470,21 +1543,21 @@ int rt_download(rt_ctx* c, double* intensity, uint8_t* rgb, int32_t* hit_prim, d
     return RT_OK;
 }
 
-int rt_tile_cuts_host(const rt_scene* scene, const rt_render_params* p, uint32_t* words, int64_t capacity_words,
-                      int32_t* tiles_x_out, int32_t* tile_log2_out) {
+int rt_tile_cuts_host(const rt_scene* scene, const rt_render_params* p, int level, uint32_t* words,
+                      int64_t capacity_words, int32_t* tiles_x_out, int32_t* level_lo, int32_t* level_top) {
     if (!scene || !p) return fail(RT_E_INVALID, "rt_tile_cuts_host: null argument");
     const rt::Scene& s = *scene->s;
     const int W = p->image_width, spp = p->samples, rows = p->row_end - p->row_begin;
     if (W < 1 || spp < 1 || rows < 1) return fail(RT_E_INVALID, "rt_tile_cuts_host: bad image");
     const int tile_log2 = pick_tile_log2(true, spp, W, rows);
-    const int ts = 1 << tile_log2;
-    const int tiles_x = (W + ts - 1) / ts;
-    const int64_t n_tiles = int64_t(tiles_x) * ((rows + ts - 1) / ts);
-    if (tiles_x_out) *tiles_x_out = tiles_x;
-    if (tile_log2_out) *tile_log2_out = tile_log2;
-    if (n_tiles > 0x7fffffff) return fail(RT_E_LIMIT, "rt_tile_cuts_host: too many tiles");
-    if (!words) return (int)n_tiles;
-    if (capacity_words < n_tiles * rtk::CUT_WORDS) return fail(RT_E_INVALID, "rt_tile_cuts_host: buffer too small");
+    const CutPlan cp = plan_cuts(W, rows, spp, tile_log2);
+    if (level_lo) *level_lo = cp.lo;
+    if (level_top) *level_top = cp.top;
+    if (level < cp.lo || level > cp.top) return fail(RT_E_INVALID, "rt_tile_cuts_host: no such level");
+    if (tiles_x_out) *tiles_x_out = cp.tiles_x[level];
+    if (cp.tiles[level] > 0x7fffffff) return fail(RT_E_LIMIT, "rt_tile_cuts_host: too many blocks");
+    if (!words) return (int)cp.tiles[level];
+    if (capacity_words < cp.tiles[level] * rtk::CUT_WORDS) return fail(RT_E_INVALID, "rt_tile_cuts_host: buffer too small");
     // camera-relative boxes, as prep_nodes_kernel computes them
     auto relative = [&](const rt::DevNode* in, size_t n) {
         std::vector<rt::DevNode> out(in, in + n);
@@ -1509,28 +1582,44 @@ int rt_tile_cuts_host(const rt_scene* scene, const rt_render_params* p, uint32_t
     ca.W = W;
     ca.rows = rows;
     ca.row0 = p->row_begin;
-    ca.tile_log2 = tile_log2;
-    ca.tiles_x = tiles_x;
-    ca.n_tiles = (int32_t)n_tiles;
-    ca.cuts = words;
-    std::memset(words, 0, size_t(n_tiles) * rtk::CUT_WORDS * sizeof(uint32_t));
-    uint32_t lists[2 * (rtk::CUT_CAP + 1)];
-    for (int64_t t = 0; t < n_tiles; ++t) rtk::tile_cut_one(ca, (int)t, lists, 1);
-    return (int)n_tiles;
+    ca.parent = nullptr;
+    ca.parent_tiles_x = 0;
+    ca.mag = rtk::cut_magnitude(ca.fp, W, p->row_begin, rows);
+    std::vector<uint32_t> prev, cur;
+    uint32_t lists[rtk::CUT_WORDS];
+    for (int l = cp.top; l >= level; --l) {
+        cur.assign(size_t(cp.tiles[l]) * rtk::CUT_WORDS, 0u);
+        ca.lvl = l;
+        ca.cap = cut_cap(l, cp);
+        ca.tiles_x = cp.tiles_x[l];
+        ca.n_tiles = (int32_t)cp.tiles[l];
+        ca.cuts = cur.data();
+        for (int64_t t = 0; t < cp.tiles[l]; ++t) rtk::cut_refine(ca, (int)t, lists, 1);
+        prev.swap(cur);
+        ca.parent = prev.data();
+        ca.parent_tiles_x = ca.tiles_x;
+    }
+    std::memcpy(words, prev.data(), prev.size() * sizeof(uint32_t));
+    return (int)cp.tiles[level];
 }
 
-int rt_last_cuts(rt_ctx* c, uint32_t* words, int64_t capacity_words, int32_t* tiles_x, int32_t* tile_log2) {
+int rt_last_cuts(rt_ctx* c, int level, uint32_t* words, int64_t capacity_words, int32_t* tiles_x, int32_t* level_lo,
+                 int32_t* level_top) {
     if (!c) return fail(RT_E_INVALID, "rt_last_cuts: null context");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (tiles_x) *tiles_x = c->cut_tiles_x;
-    if (tile_log2) *tile_log2 = c->cut_tile_log2;
-    const int64_t n = c->cut_tiles * rtk::CUT_WORDS;
-    if (words && n > 0) {
+    if (!c->cut_plan_valid) return 0;
+    const CutPlan& cp = c->cut_plan;
+    if (level_lo) *level_lo = cp.lo;
+    if (level_top) *level_top = cp.top;
+    if (level < cp.lo || level > cp.top) return fail(RT_E_INVALID, "rt_last_cuts: no such level");
+    if (tiles_x) *tiles_x = cp.tiles_x[level];
+    const int64_t n = cp.tiles[level] * rtk::CUT_WORDS;
+    if (words) {
         if (capacity_words < n) return fail(RT_E_INVALID, "rt_last_cuts: buffer too small");
-        HIP_TRY(hipMemcpy(words, c->cuts.p, size_t(n) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(words, c->cuts.p + cp.offset_words[level], size_t(n) * sizeof(uint32_t), hipMemcpyDeviceToHost));
     }
-    return (int)std::min<int64_t>(c->cut_tiles, 0x7fffffff);
+    return (int)std::min<int64_t>(cp.tiles[level], 0x7fffffff);
 }
 
 int rt_device_outputs(rt_ctx* c, void** intensity, void** rgb, void** hit_prim) {

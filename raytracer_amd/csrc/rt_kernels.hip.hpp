@@ -562,7 +562,9 @@ struct WaveCounters {
     unsigned long long tri_steps;    // triangle records fetched by the wave
 };
 
-// Entry list (tile cut, see tile_cut_kernel): n_entries < 0 -- walk from the TLAS root (the reference's own walk);
+constexpr uint32_t CUT_NODE_ENTRY = rt::DESC_TLAS | rt::DESC_ROOT;  // cut entry: BLAS node tested per ray (see "Tile cuts")
+
+// Entry list (tile cut, see cut_level_kernel): n_entries < 0 -- walk from the TLAS root (the reference's own walk);
 // otherwise lane 1 + i of `vlist` holds entry i, a descriptor at which the walk (re)starts with every valid lane
 // taking part, in the reference's visit order.  The nodes above the entries are not tested: the cut guarantees
 // that every ray of the tile reaches exactly the same leaves, in the same order, either way.
@@ -708,7 +710,18 @@ __device__ __forceinline__ void trace_packet(const PacketScene& sc, const unsign
                 SBox b;
                 int32_t left, count, first;
                 uint32_t desc;
-                if (cur & rt::DESC_TLAS) {
+                if ((cur & CUT_NODE_ENTRY) == CUT_NODE_ENTRY) {
+                    // entry of a cut: a BLAS node whose own box is tested per ray (the reference tests it when it
+                    // pops the node); lanes that pass walk on from it
+                    sload_node(sc.nodes + (cur & 0x1FFFFFFFu), b, left, count, first, desc);
+                    if (COUNT) wc.nodes += (unsigned)__builtin_popcountll(inm);
+                    const unsigned long long hm = slab_rel<FAST, OCT>(b, ix, iy, iz) & inm;
+                    if (hm != 0ull) {
+                        cur = desc;
+                        inm = hm;
+                        continue;
+                    }
+                } else if (cur & rt::DESC_TLAS) {
                     sload_node(sc.tlas + (cur & 0x3FFFFFFFu), b, left, count, first, desc);
                     if (COUNT) wc.nodes += (unsigned)__builtin_popcountll(inm);
                     const unsigned long long hm = slab_rel<FAST, OCT>(b, ix, iy, iz) & inm;
@@ -778,7 +791,11 @@ struct PacketArgs {
     // cache (its 16 KB do not survive until the same wave's next pixel); 0: wave w owns the compact quadrant w
     int32_t interleave;
     int32_t fast_ok;  // host: >= 1: every |node coordinate - camera| < 1e100; 2: and every box has min <= max
-    const uint32_t* cuts;  // per tile CUT_WORDS words written by tile_cut_kernel (header + entries), or null
+    // cuts (cut_level_kernel): level l = blocks of (1 << l)^2 pixels, cut_tx[l] blocks per row, CUT_WORDS words each;
+    // levels cut_lo .. tile_log2 are present (cut_lo < 0: no cuts, every batch walks from the root)
+    const uint32_t* cut_lvl[5];
+    int32_t cut_tx[5];
+    int32_t cut_lo;
 };
 
 // blockIdx -> tile.  `tile` already gives XCD x (blocks b == x mod 8) a contiguous run of tiles.  When the
@@ -800,67 +817,94 @@ __device__ __forceinline__ void tile_coords(const int tile, const int n_tiles, c
 }
 
 // =======================================================================================
-// Tile cuts.  All rays of an image start at the camera, and the rays of one pixel tile fill a narrow pyramid, so
-// most of the tree can be classified ONCE PER TILE instead of once per ray:
+// Tile cuts.  All rays of an image start at the camera, and the rays through one square block of pixels fill a
+// narrow pyramid, so most of the tree can be classified ONCE PER BLOCK instead of once per ray:
 //   * inside a BLAS a child's box lies inside its parent's (the builder takes unions, rtbvh.cpp:81-94, and the
-//     camera-relative subtraction and the slab products round monotonically), so in the octant-specialised slab
-//     test  tmin(parent) <= tmin(child)  and  tmax(child) <= tmax(parent)  hold exactly: a ray that passes a node's
-//     test passes the tests of all its BLAS ancestors.  The triangles a ray is tested against are therefore those
-//     of the leaves whose OWN box it passes -- internal BLAS tests only prune -- and any walk that reaches the same
-//     leaves in the same order returns the same hit, bit for bit;
+//     camera-relative subtraction and the slab products round monotonically), so in the slab test (no NaN operand)
+//     tmin(parent) <= tmin(child)  and  tmax(child) <= tmax(parent)  hold exactly: a ray that passes a node's test
+//     passes the tests of all its BLAS ancestors.  The triangles a ray is tested against are therefore those of the
+//     leaves whose OWN box it passes -- internal BLAS tests only prune -- and any walk that reaches the same leaves
+//     in the same order returns the same hit, bit for bit;
 //   * TLAS nodes guard BLAS slots they need not contain (quirk 1, rtbvh.cpp:552-560), so their tests are kept
-//     unless the whole tile provably passes or fails them.
-// tile_cut_kernel (one thread per tile) walks the tree from the TLAS root and keeps a list of descriptors in
-// visit order.  A box is classified against the tile's four corner rays (offsets -0.5 / +0.5 of its outermost
-// pixels): with the signs of the direction components fixed over the tile, "near plane a <= far plane b" reads
-//     near_a * |d_b| <= far_b * |d_a|,   both sides affine in the sample position,
-// so it holds (fails) over the whole tile iff it does at the four corners; with a relative margin of 1e-5 at the
-// corners (the rounding of the per-ray test is ~1e-15, that of the sample position is bounded below) it is SURE.
-//   sure fail  -> the entry is dropped;   sure pass / internal -> replaced by its children;
-//   unsure leaf or TLAS node -> kept (it is tested per ray: an internal node is kept when a child is an unsure leaf).
-// The render kernel starts its walk at the list's entries (trace_packet) instead of the root: the ~15 upper
-// levels of slab tests per ray are done once per tile.  Any prefix of the refinement is a valid cut, so the list
-// simply stops growing at CUT_CAP entries.  Tiles whose rays do not share an octant, or graze an axis
-// (|d_a| < 1e-4 |d|), get no cut (header 0) and are walked from the root.
+//     unless the whole block provably passes or fails them.
+// A cut is a list of entries in visit order at which the walk of a block's rays starts instead of at the TLAS root:
+//     descriptor (leaf / internal BLAS node)   every ray of the block passes this node: no test, walk on from it
+//     CUT_NODE | index                         BLAS node tested per ray (its own box), then walked from
+//     DESC_TLAS | index                        TLAS node tested per ray, as the reference does when it pops it
+// cut_level_kernel builds the cuts of one quadtree level (blocks of 2^l x 2^l pixels, one thread per block) from the
+// parent level's (the top level, one block, starts at the TLAS root): inherited entries are re-classified against
+// the smaller pyramid and refined -- a node is replaced by those of its children that are not sure to fail -- until
+// only leaves are left or the list is full (any prefix of the refinement is a valid cut).  The render kernel
+// takes, per 64-ray batch, the cut of the smallest block that holds the batch's pixels: one pixel at spp >= 64.
+//
+// Classification of a box against a block: the rays are  dd(s) = p00 + s0 row0 + s1 row1 - cam  (un-normalised;
+// the slab test is invariant under the positive scale), s in the block's sample rectangle (pixel +- 0.5, padded),
+// AFFINE in s, so |dd_a| takes its extremes at the rectangle's corners.  Per axis a the component either keeps its
+// sign over the block and stays away from zero (relative to |dd| and to the rounding of the sample position) --
+// then T_a(s) = plane_a / |dd_a(s)| lies between plane_a * wlo_a and plane_a * whi_a, w = bounds of 1 / |dd_a| --
+// or it is "mixed" (|dd_a| <= dmax_a, any sign): with the camera strictly inside the box's slab T_near_a <= 0 and
+// T_far_a >= min(-mn_a, mx_a) / dmax_a, with the camera outside it a ray that gets into the slab at all does so
+// at T_near_a >= (distance of the slab) / dmax_a and leaves it at T_far_a >= (distance of its far plane) / dmax_a.
+// The bounds are widened by 2e-5 relative (the per-ray test rounds at ~1e-15), so
+//     sure fail:  the lower bound of some T_near_a exceeds the upper bound of some T_far_b, or a far plane lies
+//                 behind the camera on a sign-keeping axis;
+//     sure pass:  every upper bound of T_near_a is <= every lower bound of T_far_b (a != b; T_near_a <= T_far_a
+//                 holds by construction) and every T_far > 0
+// for every ray of the block whose inverse direction is tame; batches with other rays (|1/d| >= 1e100, offsets
+// outside +-0.5, signs that contradict the header) walk from the root.  The bounds treat the axes independently,
+// which is loose for big blocks and tight for the few-pixel blocks the cuts are made for.
 // =======================================================================================
-constexpr int CUT_WORDS = 32;            // header + entries per tile (128 bytes)
-constexpr int CUT_CAP = CUT_WORDS - 1;   // entries
-constexpr uint32_t CUT_VALID = 0x80000000u;  // header: bit31 valid, bits 10..8 octant, bits 7..0 entry count
-constexpr int CUT_THREADS = 64;
+constexpr int CUT_WORDS = 32;                // header + entries per block (128 bytes)
+constexpr int CUT_CAP = CUT_WORDS - 1;       // entries
+constexpr uint32_t CUT_VALID = 0x80000000u;  // header: bit31 valid, bits 13..8 axis kinds (2 bits each), bits 7..0 entries
+constexpr uint32_t CUT_NODE = rt::DESC_TLAS | rt::DESC_ROOT;  // entry: BLAS node (bits 28..0) tested per ray
+constexpr int CUT_THREADS = 256;
+constexpr int CUT_MAX_LEVELS = 5;  // levels the render kernel reads: blocks of 1, 2, 4, 8, 16 pixels
 
 struct TileRays {
-    double D[4][3];  // |direction component| at the four corners (un-normalised: only ratios matter)
-    bool neg[3];     // component negative over the whole tile
+    int kind[3];             // 0: dd_a > 0 over the block, 1: < 0, 2: mixed
+    double wlo[3], whi[3];   // bounds of 1 / |dd_a| over the block, widened by the margin (mixed: whi = +inf)
 };
 
-// 0 = sure fail, 1 = sure pass, 2 = unsure.  mn/mx: camera-relative box.
+// 0 = every ray of the block fails the box, 1 = every ray passes, 2 = unsure.  mn/mx: camera-relative box.
 __host__ __device__ inline int cut_classify(const double* mn, const double* mx, const TileRays& tr) {
-    double nr[3], fr[3];
+    const double inf = __builtin_inf();
+    double nlo[3], nhi[3], flo[3], fhi[3];
+    bool pass = true;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        nr[a] = tr.neg[a] ? -mx[a] : mn[a];
-        fr[a] = tr.neg[a] ? -mn[a] : mx[a];
-    }
-    if (!(fr[0] > 0.0 && fr[1] > 0.0 && fr[2] > 0.0)) return 0;  // tmax <= 0 for every ray of the tile
-    bool all_true = true;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-#pragma unroll
-        for (int b = 0; b < 3; ++b) {
-            if (a == b) continue;
-            bool t_all = true, f_all = true;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const double A = nr[a] * tr.D[c][b], B = fr[b] * tr.D[c][a];  // B > 0
-                const double m = 1e-5 * (__builtin_fabs(A) + B);
-                t_all = t_all && (B - A >= m);
-                f_all = f_all && (A - B >= m);
+        if (tr.kind[a] == 2) {
+            const double in = __builtin_fmin(-mn[a], mx[a]);  // > 0 iff the camera is strictly inside the slab
+            if (in > 0.0) {
+                nlo[a] = -inf;
+                nhi[a] = 0.0;
+                flo[a] = in * tr.wlo[a];
+            } else {
+                nlo[a] = __builtin_fmax(mn[a], -mx[a]) * tr.wlo[a];   // >= 0
+                nhi[a] = inf;
+                flo[a] = __builtin_fmax(mx[a], -mn[a]) * tr.wlo[a];
+                pass = false;
             }
-            if (f_all) return 0;
-            all_true = all_true && t_all;
+            fhi[a] = inf;
+        } else {
+            const double nr = tr.kind[a] ? -mx[a] : mn[a];
+            const double fr = tr.kind[a] ? -mn[a] : mx[a];
+            if (!(fr > 0.0)) return 0;  // T_far_a <= 0 for every ray of the block
+            nhi[a] = nr * (nr >= 0.0 ? tr.whi[a] : tr.wlo[a]);
+            nlo[a] = nr * (nr >= 0.0 ? tr.wlo[a] : tr.whi[a]);
+            flo[a] = fr * tr.wlo[a];
+            fhi[a] = fr * tr.whi[a];
         }
     }
-    return all_true ? 1 : 2;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            if (a == b) continue;  // T_near_a <= T_far_a holds for every ray by construction
+            if (nlo[a] > fhi[b]) return 0;  // T_near_a > T_far_b for every ray of the block
+            pass = pass && (nhi[a] <= flo[b]);
+        }
+    return pass ? 1 : 2;
 }
 
 struct CutArgs {
@@ -868,176 +912,181 @@ struct CutArgs {
     const rt::DevNode* tlas;   // camera-relative
     const int32_t* slot_root;
     FrameParams fp;
-    int32_t W, rows, row0, tile_log2, tiles_x, n_tiles;
-    uint32_t* cuts;
+    int32_t W, rows, row0;
+    int32_t lvl;               // blocks of (1 << lvl)^2 pixels
+    int32_t tiles_x, n_tiles;  // of this level
+    const uint32_t* parent;    // cuts of level lvl + 1 (parent_tiles_x blocks per row), or null: start at the root
+    int32_t parent_tiles_x;
+    double mag;                // bound of the magnitudes any sample position of the image is computed from
+    int32_t cap;               // entries a list of this level may hold (<= CUT_CAP)
+    uint32_t* cuts;            // n_tiles * CUT_WORDS
 };
 
-// One tile's cut.  `lists`: two lists of CUT_CAP + 1 words, element (buffer, i) at lists[(buffer * (CUT_CAP + 1) + i) *
-// stride] (the kernel interleaves the threads of a workgroup in LDS; the host test seam passes stride 1).
-__host__ __device__ inline void tile_cut_one(const CutArgs& a, const int tile, uint32_t* const lists, const int stride) {
-#define RT_CUT_LIST(BUF, I) lists[((BUF) * (CUT_CAP + 1) + (I)) * stride]
-    const int ts = 1 << a.tile_log2;
-    const int tix = tile % a.tiles_x, tiy = tile / a.tiles_x;
-    uint32_t* const out = a.cuts + (size_t)tile * CUT_WORDS;
+// max over the image's sample positions and components of |p00| + |s0 row0| + |s1 row1| + |cam|
+__host__ __device__ inline double cut_magnitude(const FrameParams& fp, const int W, const int row0, const int rows) {
+    double mag = 0.0;
+    const double s0 = (double)W + 1.0, s1 = (double)(row0 + rows) + 1.0;
+    for (int k = 0; k < 3; ++k) {
+        const double v = __builtin_fabs(fp.p00[k]) + __builtin_fabs(s0 * fp.sp[k]) + __builtin_fabs(s1 * fp.sp[3 + k]) +
+                         __builtin_fabs(fp.cam[k]);
+        mag = v > mag ? v : mag;
+        if (!(v == v)) mag = __builtin_inf();  // NaN camera: no cuts
+    }
+    return mag;
+}
 
-    // the tile's corner rays: sample positions px + [-0.5, 0.5] (cpp/rtrender.cpp:53-56), a little padded
-    TileRays tr;
-    bool valid = true;
-    {
-        const double pad = 0.5 + 0x1p-20;
-        const double s0v[2] = {(double)(tix * ts) - pad, (double)(tix * ts + ts - 1) + pad};
-        const double s1v[2] = {(double)(tiy * ts + a.row0) - pad, (double)(tiy * ts + ts - 1 + a.row0) + pad};
-        double dd[4][3];
-        double mag = 0.0;  // bounds the magnitudes the per-ray sample position is computed from
+// The sample rectangle of a block and its corner rays.  false: no cut for this block (degenerate camera).
+__host__ __device__ inline bool cut_tile_rays(const CutArgs& a, const int tix, const int tiy, TileRays& tr) {
+    const int ts = 1 << a.lvl;
+    // sample positions px + [-0.5, 0.5] (cpp/rtrender.cpp:53-56), a little padded; blocks of the image's last
+    // column / row are cut to the image
+    const int x1 = (tix * ts + ts - 1 < a.W - 1) ? tix * ts + ts - 1 : a.W - 1;
+    const int y1 = (tiy * ts + ts - 1 < a.rows - 1) ? tiy * ts + ts - 1 : a.rows - 1;
+    const double pad = 0.5 + 0x1p-20;
+    const double s0v[2] = {(double)(tix * ts) - pad, (double)x1 + pad};
+    const double s1v[2] = {(double)(tiy * ts + a.row0) - pad, (double)(y1 + a.row0) + pad};
+    double dd[4][3];
+    const double mag = a.mag;  // (host: cut_magnitude) bounds what the per-ray sample position is computed from
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const double s0 = s0v[c & 1], s1 = s1v[c >> 1];
+    for (int c = 0; c < 4; ++c) {
+        const double s0 = s0v[c & 1], s1 = s1v[c >> 1];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                dd[c][k] = ((a.fp.p00[k] + s0 * a.fp.sp[k]) + s1 * a.fp.sp[3 + k]) - a.fp.cam[k];
-                mag = __builtin_fmax(mag, __builtin_fabs(a.fp.p00[k]) + __builtin_fabs(s0 * a.fp.sp[k]) +
-                                              __builtin_fabs(s1 * a.fp.sp[3 + k]) + __builtin_fabs(a.fp.cam[k]));
-            }
-        }
-        double big = 0.0;
+        for (int k = 0; k < 3; ++k) dd[c][k] = ((a.fp.p00[k] + s0 * a.fp.sp[k]) + s1 * a.fp.sp[3 + k]) - a.fp.cam[k];
+    }
+    double big = 0.0;
+    bool finite = true;
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int k = 0; k < 3; ++k) big = __builtin_fmax(big, __builtin_fabs(dd[c][k]));
-        // every component keeps its sign over the tile and stays well away from zero: relative to the direction
-        // (no grazing rays: |1/d| stays tame) and relative to the rounding of the sample position (2^-50 mag)
-        const double floor_abs = __builtin_fmax(1e-4 * big, 1e7 * 0x1p-50 * mag);
+    for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const bool ng = dd[0][k] < 0.0;
-            tr.neg[k] = ng;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const double v = ng ? -dd[c][k] : dd[c][k];
-                tr.D[c][k] = v;
-                valid = valid && (v >= floor_abs) && (v < 1e100);  // NaN / inf / sign change -> false
-            }
+            const double v = __builtin_fabs(dd[c][k]);
+            big = __builtin_fmax(big, v);
+            finite = finite && (v < 1e100);  // NaN / inf -> false
         }
-        valid = valid && big > 0.0;
+    if (!finite || !(big > 0.0) || !(mag < 1e100)) return false;
+    // a component "keeps its sign" when it does so with room: relative to the direction (no grazing rays) and to
+    // the rounding of the sample position (a few ulps of `mag`)
+    const double eta = 0x1p-50 * mag;
+    const double floor_abs = __builtin_fmax(1e-4 * big, 1e7 * eta);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const bool ng = dd[0][k] < 0.0;
+        bool uniform = true;
+        double lo = __builtin_inf(), hi = 0.0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const double v = ng ? -dd[c][k] : dd[c][k];
+            uniform = uniform && (v >= floor_abs);
+            lo = __builtin_fmin(lo, __builtin_fabs(dd[c][k]));
+            hi = __builtin_fmax(hi, __builtin_fabs(dd[c][k]));  // |dd_k(s)| is convex in s: its maximum is at a corner
+        }
+        tr.kind[k] = uniform ? (ng ? 1 : 0) : 2;
+        // sign-keeping: |dd_k| >= 1e7 eta at the corners, the rounding of the sample position moves it by < 1e-7
+        // relative; mixed: the bound of |dd_k| gets the absolute slack
+        const double dmax = uniform ? hi : hi * (1.0 + 1e-5) + 1e7 * eta;
+        tr.wlo[k] = (1.0 / dmax) * (1.0 - 2e-5);
+        tr.whi[k] = uniform ? (1.0 / lo) * (1.0 + 2e-5) : __builtin_inf();
     }
-    if (!valid) {
+    return true;
+}
+
+// One block's cut: a depth-first refinement of the inherited list (the top level: of the TLAS root) that emits the
+// entries in visit order.  `stk`: CUT_WORDS words, element i at stk[i * stride] (the kernel interleaves the threads
+// of a workgroup in LDS; the host twin passes stride 1).  Every step takes one waiting entry and, unless it is
+// already known to be passed by every ray, loads ONE node record and classifies ONE box -- the same work in every
+// lane of a wave, whatever the kinds of their entries.  An entry is replaced by its children only while the list
+// is sure to fit (entries written + entries waiting + 2 <= cap), so the walk never runs out of room: whatever is
+// not refined is emitted as it is, which is a valid cut too.
+__host__ __device__ inline void cut_refine(const CutArgs& a, const int tile, uint32_t* const stk, const int stride) {
+    const int tix = tile % a.tiles_x, tiy = tile / a.tiles_x;
+    uint32_t* const out = a.cuts + (size_t)tile * CUT_WORDS;
+    TileRays tr;
+    if (!cut_tile_rays(a, tix, tiy, tr)) {
         out[0] = 0u;
         return;
     }
-
-    // refinement rounds over a list in visit order; `fin` bit i: entry i cannot be refined further
-    int cur = 0, n = 1;
-    uint32_t fin = 0u;
-    RT_CUT_LIST(0, 0) = rt::DESC_TLAS;
-    for (int round = 0; round < 96; ++round) {
-        bool changed = false;
-        int m = 0;
-        uint32_t fin2 = 0u;
-        for (int i = 0; i < n; ++i) {
-            const uint32_t e = RT_CUT_LIST(cur, i);
-            const int rest = n - 1 - i;  // entries still to be copied / refined after this one
-            uint32_t r0 = 0u, r1 = 0u;  // replacement entries, in visit order
-            bool f0 = false, f1 = false;  // ... that cannot be refined further
-            int k = -1;  // number of replacement entries; -1: keep e as it is (final)
-            bool retry = false;  // keep e, but it may be refined in a later round (no room now)
-            if (!((fin >> i) & 1u)) {
-                if (e & rt::DESC_LEAF) {
-                    k = -1;
-                } else if (e & rt::DESC_TLAS) {
-                    const rt::DevNode nd = a.tlas[e & 0x3FFFFFFFu];
-                    const int cls = cut_classify(nd.mn, nd.mx, tr);
-                    if (cls == 0) {
-                        k = 0;
-                    } else if (cls == 1) {
-                        if (nd.left < 0) {
-                            if (nd.count >= 1 && nd.count <= 2) {  // the slots of a TLAS leaf, in visit order
-                                k = nd.count;
-                                r0 = rt::DESC_ROOT | (uint32_t)nd.first;
-                                r1 = rt::DESC_ROOT | (uint32_t)(nd.first + 1);
-                            }
-                        } else {
-                            k = 2;
-                            r0 = rt::DESC_TLAS | (uint32_t)nd.left;
-                            r1 = rt::DESC_TLAS | (uint32_t)(nd.left + 1);
-                        }
-                    }
-                } else if (e & rt::DESC_ROOT) {
-                    const rt::DevNode nd = a.nodes[a.slot_root[e & 0x1FFFFFFFu]];
-                    const int cls = cut_classify(nd.mn, nd.mx, tr);
-                    const bool leaf = (nd.desc & rt::DESC_LEAF) != 0u;
-                    if (cls == 0) {
-                        k = 0;
-                    } else if (cls == 1 || !leaf) {
-                        k = 1;  // the root's own test only prunes (BLAS monotonicity); a passing leaf root is final
-                        r0 = nd.desc;
-                        f0 = leaf;
-                    }
-                } else {
-                    // internal BLAS node: e = index of its left child, the right one is adjacent
-                    const rt::DevNode nl = a.nodes[e];
-                    const rt::DevNode nr = a.nodes[e + 1u];
-                    const int cl = cut_classify(nl.mn, nl.mx, tr);
-                    const int cr = cut_classify(nr.mn, nr.mx, tr);
-                    const bool ll = (nl.desc & rt::DESC_LEAF) != 0u, lr = (nr.desc & rt::DESC_LEAF) != 0u;
-                    // an unsure leaf is tested per ray, by its parent's step: then the parent stays
-                    if (!((cl == 2 && ll) || (cr == 2 && lr))) {
-                        k = 0;
-                        if (cl != 0) {
-                            r0 = nl.desc;
-                            f0 = ll;
-                            k = 1;
-                        }
-                        if (cr != 0) {
-                            if (k == 0) {
-                                r0 = nr.desc;
-                                f0 = lr;
-                            } else {
-                                r1 = nr.desc;
-                                f1 = lr;
-                            }
-                            ++k;
-                        }
-                    }
-                }
-                if (k >= 0 && m + k + rest > CUT_CAP) {
-                    k = -1;
-                    retry = true;
-                }
-            }
-            if (k < 0) {
-                RT_CUT_LIST(cur ^ 1, m) = e;
-                if (!retry) fin2 |= 1u << m;
-                ++m;
-            } else {
-                changed = true;
-                if (k >= 1) {
-                    RT_CUT_LIST(cur ^ 1, m) = r0;
-                    if (f0) fin2 |= 1u << m;
-                    ++m;
-                }
-                if (k >= 2) {
-                    RT_CUT_LIST(cur ^ 1, m) = r1;
-                    if (f1) fin2 |= 1u << m;
-                    ++m;
-                }
-            }
-        }
-        cur ^= 1;
-        n = m;
-        fin = fin2;
-        if (!changed) break;
+    int sp = 0;  // entries waiting, the next one on top
+    const uint32_t* par = nullptr;
+    if (a.parent) {
+        par = a.parent + ((size_t)(tiy >> 1) * a.parent_tiles_x + (tix >> 1)) * CUT_WORDS;
+        if (!(par[0] & CUT_VALID)) par = nullptr;
     }
-    const int oct = (tr.neg[0] ? 1 : 0) | (tr.neg[1] ? 2 : 0) | (tr.neg[2] ? 4 : 0);
-    out[0] = CUT_VALID | ((uint32_t)oct << 8) | (uint32_t)n;
-    for (int i = 0; i < n; ++i) out[1 + i] = RT_CUT_LIST(cur, i);
-#undef RT_CUT_LIST
+    if (par) {
+        const int pn = (int)(par[0] & 0xffu);
+        for (int i = pn - 1; i >= 0; --i) stk[(sp++) * stride] = par[1 + i];
+    } else {
+        stk[0] = rt::DESC_TLAS;
+        sp = 1;
+    }
+    int n = 0;  // entries written
+    while (sp > 0) {
+        --sp;
+        const uint32_t e = stk[sp * stride];
+        const uint32_t kind = e & CUT_NODE;
+        const bool room = n + sp + 2 <= a.cap;
+        if ((e & rt::DESC_LEAF) || kind == 0u) {
+            // every ray of the block passes this node: a leaf is final, an internal node (e = index of its left
+            // child) gives way to its children, whose boxes are classified when their turn comes
+            if (!(e & rt::DESC_LEAF) && room) {
+                stk[(sp++) * stride] = CUT_NODE | (e + 1u);
+                stk[(sp++) * stride] = CUT_NODE | e;
+            } else {
+                out[1 + n++] = e;
+            }
+            continue;
+        }
+        // an entry with a box of its own: TLAS node, root of a BLAS slot (its test is the test of that node) or
+        // BLAS node
+        const bool is_tlas = kind == rt::DESC_TLAS;
+        uint32_t idx = e & 0x1FFFFFFFu;
+        if (kind == rt::DESC_ROOT) idx = (uint32_t)a.slot_root[idx];
+        const rt::DevNode* const np = is_tlas ? a.tlas + (e & 0x3FFFFFFFu) : a.nodes + idx;
+        double mn[3], mx[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            mn[k] = np->mn[k];
+            mx[k] = np->mx[k];
+        }
+        const int32_t left = np->left, count = np->count, first = np->first;
+        const uint32_t desc = np->desc;
+        const int cls = cut_classify(mn, mx, tr);
+        if (cls == 0) continue;  // no ray of the block passes it
+        if (is_tlas) {
+            // kept (tested per ray, as the reference does when it pops the node) unless every ray passes it
+            if (cls == 1 && left >= 0 && room) {
+                stk[(sp++) * stride] = rt::DESC_TLAS | (uint32_t)(left + 1);
+                stk[(sp++) * stride] = rt::DESC_TLAS | (uint32_t)left;
+            } else if (cls == 1 && left < 0 && count >= 1 && count <= 2 && room) {
+                for (int q = count - 1; q >= 0; --q) stk[(sp++) * stride] = rt::DESC_ROOT | (uint32_t)(first + q);
+            } else {
+                out[1 + n++] = e;
+            }
+            continue;
+        }
+        if (!(desc & rt::DESC_LEAF) && room) {
+            // internal: gives way to its children (its own test, sure or not, only prunes), the left one on top
+            stk[(sp++) * stride] = CUT_NODE | (desc + 1u);
+            stk[(sp++) * stride] = CUT_NODE | desc;
+        } else {
+            out[1 + n++] = (cls == 1) ? desc : (CUT_NODE | idx);
+        }
+    }
+    out[0] = CUT_VALID | ((uint32_t)tr.kind[0] << 8) | ((uint32_t)tr.kind[1] << 10) | ((uint32_t)tr.kind[2] << 12) |
+             (uint32_t)n;
 }
 
-__global__ __launch_bounds__(CUT_THREADS) void tile_cut_kernel(const CutArgs a) {
-    __shared__ uint32_t s_list[2 * (CUT_CAP + 1) * CUT_THREADS];  // [buffer][entry][thread]: conflict-free
-    const int tile = blockIdx.x * CUT_THREADS + threadIdx.x;
-    if (tile >= a.n_tiles) return;
-    tile_cut_one(a, tile, s_list + threadIdx.x, CUT_THREADS);
+// One thread per block.  A wave takes an 8 x 8 patch of blocks (16 parents, neighbouring parts of the tree: its
+// loads hit each other's lines in the vector L1), a workgroup a row of four patches.
+__global__ __launch_bounds__(CUT_THREADS) void cut_level_kernel(const CutArgs a) {
+    __shared__ uint32_t s_stk[CUT_WORDS * CUT_THREADS];  // [entry][thread]: conflict-free
+    const int patches_x = (a.tiles_x + 7) >> 3;
+    const int patch = blockIdx.x * (CUT_THREADS / 64) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int tix = ((patch % patches_x) << 3) + (lane & 7);
+    const int tiy = ((patch / patches_x) << 3) + (lane >> 3);
+    const int tiles_y = a.n_tiles / a.tiles_x;
+    if (tix >= a.tiles_x || tiy >= tiles_y) return;
+    cut_refine(a, tiy * a.tiles_x + tix, s_stk + threadIdx.x, CUT_THREADS);
 }
 
 // ---- the compiler's fp64 division, for operands that need no scaling (see render_packet_kernel) ----
@@ -1130,14 +1179,6 @@ __global__ __launch_bounds__(NT, 8) void render_packet_kernel(const PacketArgs a
     unsigned long long w_nodes = 0, w_tris = 0, w_steps = 0, w_tsteps = 0;  // lane 0 of each wave carries the wave's sums
     uint32_t n_hits = 0;
 
-    // the tile's cut (tile_cut_kernel): lane 0 = header, lanes 1.. = entries; one VGPR for the whole tile
-    uint32_t vcut = 0;
-    {
-        const uint32_t* const cuts = karg_ptr<const uint32_t, offsetof(PacketArgs, cuts)>();
-        if (cuts && lane < CUT_WORDS) vcut = cuts[(size_t)(tiy * a.tiles_x + tix) * CUT_WORDS + lane];
-    }
-    const uint32_t cut_hdr = (uint32_t)__builtin_amdgcn_readfirstlane((int)vcut);
-
     // The jitter pair of the NEXT batch is requested before this batch is traversed (one HBM round trip
     // off every batch's critical path: the kernel is bound by per-wave latency at 8 waves per SIMD).
     struct Slot {
@@ -1145,6 +1186,7 @@ __global__ __launch_bounds__(NT, 8) void render_packet_kernel(const PacketArgs a
         bool active;
         size_t sidx;
         d2 jit;
+        uint32_t vcut;  // the batch's cut: lane 0 = header, lanes 1.. = entries (0: none)
     };
     auto fetch = [&](const int base) {
         Slot q;
@@ -1160,6 +1202,33 @@ __global__ __launch_bounds__(NT, 8) void render_packet_kernel(const PacketArgs a
         // streamed once: non-temporal, so the 16 B/sample stream does not displace tree nodes in L2
         if (q.active)
             q.jit = __builtin_nontemporal_load(karg_ptr<const d2, offsetof(PacketArgs, jitter)>() + q.sidx);
+        // the cut of the smallest aligned pixel block that holds the batch's pixels (Morton indices m of its first
+        // and last ray: an aligned block is an interval of Morton indices)
+        q.vcut = 0u;
+        if (a.cut_lo >= 0) {
+            const int last = min(63, n_rays - 1 - base);
+            const int mf = __builtin_amdgcn_readfirstlane(m), ml2 = P64 ? mf : __builtin_amdgcn_readlane(m, last);
+            const int pxf = __builtin_amdgcn_readfirstlane(q.px), pyf = __builtin_amdgcn_readfirstlane(q.py);
+            const int pxl = P64 ? pxf : __builtin_amdgcn_readlane(q.px, last);
+            const int pyl = P64 ? pyf : __builtin_amdgcn_readlane(q.py, last);
+            const uint32_t x = (uint32_t)(mf ^ ml2);
+            int lvl = x ? ((31 - __builtin_clz(x)) >> 1) + 1 : 0;
+            lvl = max(lvl, a.cut_lo);
+            if (pxf < a.W && pyf < a.rows && pxl < a.W && pyl < a.rows) {
+                unsigned long long base_ptr;
+                uint32_t ctx;
+                const auto kseg = __builtin_amdgcn_kernarg_segment_ptr();
+                const uint32_t o1 = (uint32_t)offsetof(PacketArgs, cut_lvl) + 8u * (uint32_t)lvl;
+                const uint32_t o2 = (uint32_t)offsetof(PacketArgs, cut_tx) + 4u * (uint32_t)lvl;
+                asm volatile("s_load_dwordx2 %0, %2, %3\n\ts_load_dword %1, %2, %4\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&s"(base_ptr), "=&s"(ctx)
+                             : "s"(kseg), "s"(o1), "s"(o2)
+                             : "memory");
+                const uint32_t* const cp = reinterpret_cast<const uint32_t*>(base_ptr) +
+                                           ((size_t)(pyf >> lvl) * ctx + (size_t)(pxf >> lvl)) * CUT_WORDS;
+                if (lane < CUT_WORDS) q.vcut = cp[lane];
+            }
+        }
         return q;
     };
     Slot nxt = fetch(0);
@@ -1256,21 +1325,27 @@ __global__ __launch_bounds__(NT, 8) void render_packet_kernel(const PacketArgs a
             const unsigned long long ngz = __builtin_amdgcn_ballot_w64(iz < 0.0) & amask;
             const bool uni = (ngx == 0ull || ngx == amask) && (ngy == 0ull || ngy == amask) &&
                              (ngz == 0ull || ngz == amask) && a.fast_ok == 2;
+            // The batch's cut holds for rays through its block with offsets in [-0.5, 0.5] whose direction signs are
+            // the ones it was computed for, and no NaN-prone lane (caller-supplied offsets may be anything).
+            int n_ent = -1;
+            const uint32_t cut_hdr = (uint32_t)__builtin_amdgcn_readfirstlane((int)cs.vcut);
+            if (cut_hdr & CUT_VALID) {
+                const uint32_t kx = (cut_hdr >> 8) & 3u, ky = (cut_hdr >> 10) & 3u, kz = (cut_hdr >> 12) & 3u;
+                const bool sx_ok = kx == 2u || (kx == 1u ? ngx == amask : ngx == 0ull);
+                const bool sy_ok = ky == 2u || (ky == 1u ? ngy == amask : ngy == 0ull);
+                const bool sz_ok = kz == 2u || (kz == 1u ? ngz == amask : ngz == 0ull);
+                const bool in_range = __builtin_fabs(cs.jit.x) <= 0.5 && __builtin_fabs(cs.jit.y) <= 0.5;
+                if (sx_ok && sy_ok && sz_ok && (__builtin_amdgcn_ballot_w64(!in_range) & amask) == 0ull)
+                    n_ent = (int)(cut_hdr & 0xffu);
+            }
             if (__builtin_amdgcn_ballot_w64(risky) != 0ull) {
                 trace_packet<false, -1, COUNT>(a.sc, amask, dx, dy, dz, ix, iy, iz, wstk, h, wc, 0u, -1);
             } else if (uni) {
                 const int oct = (ngx != 0ull ? 1 : 0) | (ngy != 0ull ? 2 : 0) | (ngz != 0ull ? 4 : 0);
-                // The tile's cut holds for rays through the tile's pixels with offsets in [-0.5, 0.5] that all look
-                // into the octant it was computed for (caller-supplied offsets may be anything: checked here).
-                int n_ent = -1;
-                if ((cut_hdr & CUT_VALID) && (int)((cut_hdr >> 8) & 7u) == oct) {
-                    const bool in_range = __builtin_fabs(cs.jit.x) <= 0.5 && __builtin_fabs(cs.jit.y) <= 0.5;
-                    if ((__builtin_amdgcn_ballot_w64(!in_range) & amask) == 0ull) n_ent = (int)(cut_hdr & 0xffu);
-                }
                 switch (oct) {
-#define RT_OCT_CASE(O)                                                                                    \
-    case O:                                                                                               \
-        trace_packet<true, O, COUNT>(a.sc, amask, dx, dy, dz, ix, iy, iz, wstk, h, wc, vcut, n_ent);     \
+#define RT_OCT_CASE(O)                                                                                       \
+    case O:                                                                                                  \
+        trace_packet<true, O, COUNT>(a.sc, amask, dx, dy, dz, ix, iy, iz, wstk, h, wc, cs.vcut, n_ent);     \
         break;
                     RT_OCT_CASE(0)
                     RT_OCT_CASE(1)
@@ -1283,7 +1358,9 @@ __global__ __launch_bounds__(NT, 8) void render_packet_kernel(const PacketArgs a
 #undef RT_OCT_CASE
                 }
             } else {
-                trace_packet<true, -1, COUNT>(a.sc, amask, dx, dy, dz, ix, iy, iz, wstk, h, wc, 0u, -1);
+                // mixed signs: the general slab test (min/max per axis), every product finite
+                trace_packet<true, -1, COUNT>(a.sc, amask, dx, dy, dz, ix, iy, iz, wstk, h, wc, cs.vcut,
+                                              a.fast_ok == 2 ? n_ent : -1);
             }
             if (COUNT && lane == 0) {
                 w_nodes += wc.nodes;
