@@ -82,6 +82,7 @@ struct DevBuf {
 // single block of level `top` down to level `lo`, the finest one a 64-ray batch can ask for.
 struct CutPlan {
     int lo = 0, top = 0;
+    bool present[32] = {};  // levels that are made (top, lo and, with RT_CUT_STEP=1, every level in between)
     int tiles_x[32] = {};
     int64_t tiles[32] = {};
     int64_t offset_words[32] = {};
@@ -91,7 +92,7 @@ struct CutPlan {
 // Entries a list of level l may hold: coarse levels only hand a starting point down (their blocks are refined
 // again, four times over, by their children), so they stop at half the room.
 int cut_cap(int l, const CutPlan& cp) {
-    static const int top_cap = std::getenv("RT_CUT_TOPCAP") ? std::atoi(std::getenv("RT_CUT_TOPCAP")) : 15;  // (tuning knob)
+    const int top_cap = std::getenv("RT_CUT_TOPCAP") ? std::atoi(std::getenv("RT_CUT_TOPCAP")) : 15;  // (tuning knob)
     return (l > cp.lo + 1) ? std::max(1, std::min(top_cap, (int)rtk::CUT_CAP)) : (int)rtk::CUT_CAP;
 }
 
@@ -113,7 +114,11 @@ CutPlan plan_cuts(int W, int rows, int spp, int tile_log2) {
     int whole = 0;
     while ((1 << whole) < std::max(W, rows)) ++whole;
     cp.top = std::max(cp.lo, std::min(cp.top, std::max(whole, tile_log2)));
+    const int step = std::getenv("RT_CUT_STEP") ? std::max(1, std::atoi(std::getenv("RT_CUT_STEP"))) : 2;  // (tuning knob)
     for (int l = cp.top; l >= cp.lo; --l) {
+        // every `step`-th level below the top, and the finest one
+        if (l != cp.lo && (cp.top - l) % step != 0) continue;
+        cp.present[l] = true;
         const int ts = 1 << l;
         cp.tiles_x[l] = (W + ts - 1) / ts;
         cp.tiles[l] = int64_t(cp.tiles_x[l]) * ((rows + ts - 1) / ts);
@@ -182,6 +187,8 @@ struct rt_ctx {
     DevBuf<double> prev_intensity;
     DevBuf<uint8_t> prev_rgb;
     hipEvent_t out_done = nullptr, prev_out_done = nullptr;  // traversal kernel of the last / previous launch
+    hipEvent_t cuts_done = nullptr;  // the cut kernels of the last launch (the sampler's look-ahead waits for them)
+    bool cuts_done_pending = false;
     size_t n_nodes = 0, n_tlas = 0;
     double max_abs_coord = 0.0;  // largest |coordinate| of the uploaded scene (NaN/inf -> inf)
     int32_t stack_need = 1;
@@ -768,7 +775,8 @@ rt_ctx* rt_create(int device) {
         hipEventCreateWithFlags(&c->front_last_use, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->back_last_use, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->out_done, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->prev_out_done, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->prev_out_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->cuts_done, hipEventDisableTiming) != hipSuccess) {
         g_err = "rt_create: copy stream / events";
         return nullptr;
     }
@@ -877,6 +885,7 @@ void rt_destroy(rt_ctx* c) {
     c->back.colors.release();
     if (c->out_done) (void)hipEventDestroy(c->out_done);
     if (c->prev_out_done) (void)hipEventDestroy(c->prev_out_done);
+    if (c->cuts_done) (void)hipEventDestroy(c->cuts_done);
     c->prev_intensity.release();
     c->prev_rgb.release();
     if (c->front_last_use) (void)hipEventDestroy(c->front_last_use);
@@ -1031,7 +1040,8 @@ struct PacketBuffers {
 };
 
 // prep kernels + render_packet_kernel on c->stream, bracketed by the context's timing events.  Allocates nothing.
-int launch_packet(rt_ctx* c, const rt_render_params* p, int tile_log2, int tiles_x, int64_t n_tiles, const PacketBuffers& pb) {
+int launch_packet(rt_ctx* c, const rt_render_params* p, int tile_log2, int tiles_x, int64_t n_tiles, const PacketBuffers& pb,
+                  bool* cuts_made = nullptr) {
     const int W = p->image_width, spp = p->samples, rows = p->row_end - p->row_begin;
     const bool count = pb.counters != nullptr;
     const double ox = p->camera_center[0], oy = p->camera_center[1], oz = p->camera_center[2];
@@ -1086,8 +1096,13 @@ int launch_packet(rt_ctx* c, const rt_render_params* p, int tile_log2, int tiles
     for (int l = 0; l < rtk::CUT_MAX_LEVELS; ++l) {
         a.cut_lvl[l] = nullptr;
         a.cut_tx[l] = 0;
+        a.cut_eff[l] = l;
     }
-    if (pb.cuts && !count && a.fast_ok == 2 && !no_cut) {
+    // The cut kernels are chains of dependent steps (~0.3 ms however small the image) and save about a third of the
+    // traversal: they pay from a few ms of traversal on.  Measured break-even: ~30 M rays (1024 x 576 x 50).
+    const char* mr = std::getenv("RT_CUT_MIN_RAYS");  // (tuning knob)
+    const double min_rays = mr ? std::atof(mr) : 64e6;
+    if (pb.cuts && !count && a.fast_ok == 2 && !no_cut && double(rows) * W * spp >= min_rays) {
         const CutPlan cp = plan_cuts(W, rows, spp, tile_log2);
         rtk::CutArgs ca;
         ca.nodes = pb.cam_nodes;
@@ -1100,8 +1115,12 @@ int launch_packet(rt_ctx* c, const rt_render_params* p, int tile_log2, int tiles
         ca.parent = nullptr;
         ca.parent_tiles_x = 0;
         ca.mag = rtk::cut_magnitude(ca.fp, W, p->row_begin, rows);
+        int parent_lvl = -1;
         for (int l = cp.top; l >= cp.lo; --l) {  // each level from its parent's cuts, the top one from the root
+            if (!cp.present[l]) continue;
             ca.lvl = l;
+            ca.parent_shift = parent_lvl < 0 ? 0 : parent_lvl - l;
+            parent_lvl = l;
             ca.cap = cut_cap(l, cp);
             ca.tiles_x = cp.tiles_x[l];
             ca.n_tiles = (int32_t)cp.tiles[l];
@@ -1112,14 +1131,24 @@ int launch_packet(rt_ctx* c, const rt_render_params* p, int tile_log2, int tiles
                                dim3(rtk::CUT_THREADS), 0, c->stream, ca);
             ca.parent = ca.cuts;
             ca.parent_tiles_x = ca.tiles_x;
-            if (l < rtk::CUT_MAX_LEVELS) {
-                a.cut_lvl[l] = ca.cuts;
-                a.cut_tx[l] = ca.tiles_x;
-            }
         }
         HIP_TRY(hipGetLastError());
+        // what a batch finds at level l: that level's cuts, or those of the next coarser level that was made
+        for (int l = cp.lo; l <= tile_log2 && l < rtk::CUT_MAX_LEVELS; ++l) {
+            int e = l;
+            while (!cp.present[e]) ++e;  // the top level (>= tile_log2) always is
+            if (e >= rtk::CUT_MAX_LEVELS + 27) break;
+            a.cut_lvl[l] = pb.cuts + cp.offset_words[e];
+            a.cut_tx[l] = cp.tiles_x[e];
+            a.cut_eff[l] = e;
+        }
         a.cut_lo = cp.lo;
+        // the sampler's look-ahead kernels (next frame's jitter, own stream) may overlap the long traversal kernel,
+        // not these short latency-bound ones: they slow each other down by 2x
+        HIP_TRY(hipEventRecord(c->cuts_done, c->stream));
+        c->cuts_done_pending = true;
     }
+    if (cuts_made) *cuts_made = a.cut_lo >= 0;
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     if (count && a.pair64)
         hipLaunchKernelGGL((rtk::render_packet_kernel<true, true>), dim3((unsigned)n_tiles), dim3(rtk::NT), 0, c->stream, a);
@@ -1322,9 +1351,10 @@ int render_impl(rt_ctx* c, const rt_render_params* p, bool pipelined) {
         if (cp.tiles[cp.lo] > 0x7fffffff) return fail(RT_E_LIMIT, "rt_render: too many pixel blocks");
         if ((rc = c->cuts.ensure(size_t(cp.total_words)))) return rc;
         pb.cuts = c->cuts.p;
-        if ((rc = launch_packet(c, p, tile_log2, tiles_x, n_tiles, pb))) return rc;
+        bool cuts_made = false;
+        if ((rc = launch_packet(c, p, tile_log2, tiles_x, n_tiles, pb, &cuts_made))) return rc;
         c->cut_plan = cp;
-        c->cut_plan_valid = !count;
+        c->cut_plan_valid = cuts_made;
     } else {
         // Per-lane traversal: trees deeper than the packet kernel's 64 pending bits, or forced.
         rtk::RenderArgs a;
@@ -1385,6 +1415,12 @@ int render_impl(rt_ctx* c, const rt_render_params* p, bool pipelined) {
                 if (delta >= uint64_t(n_smp) * 4u) next = start_pos + delta;
             }
             const int other = 1 - use;
+            // (measured: making the look-ahead wait for the cut kernels halves their time -- both are latency-bound
+            // and slow each other down -- but the sampler then overlaps the traversal kernel for longer, which is
+            // bound by the same VALU issue slots: 27.3 instead of 26.4 ms per 4096^2 x 64 frame.  RT_LOOKAHEAD_AFTER_CUTS=1)
+            if (c->cuts_done_pending && std::getenv("RT_LOOKAHEAD_AFTER_CUTS"))
+                HIP_TRY(hipStreamWaitEvent(c->rng_stream, c->cuts_done, 0));
+            c->cuts_done_pending = false;
             // slot `other` was last read by the previous call's kernel: fill_slot makes rng_stream wait
             // for it (read_done); the slot's own jitter kernel is ordered on rng_stream.
             if ((rc = fill_slot(c, other, next - c->pos, rows, W, spp))) return rc;
@@ -1553,7 +1589,7 @@ int rt_tile_cuts_host(const rt_scene* scene, const rt_render_params* p, int leve
     const CutPlan cp = plan_cuts(W, rows, spp, tile_log2);
     if (level_lo) *level_lo = cp.lo;
     if (level_top) *level_top = cp.top;
-    if (level < cp.lo || level > cp.top) return fail(RT_E_INVALID, "rt_tile_cuts_host: no such level");
+    if (level < cp.lo || level > cp.top || !cp.present[level]) return fail(RT_E_INVALID, "rt_tile_cuts_host: no such level");
     if (tiles_x_out) *tiles_x_out = cp.tiles_x[level];
     if (cp.tiles[level] > 0x7fffffff) return fail(RT_E_LIMIT, "rt_tile_cuts_host: too many blocks");
     if (!words) return (int)cp.tiles[level];
@@ -1587,9 +1623,13 @@ int rt_tile_cuts_host(const rt_scene* scene, const rt_render_params* p, int leve
     ca.mag = rtk::cut_magnitude(ca.fp, W, p->row_begin, rows);
     std::vector<uint32_t> prev, cur;
     uint32_t lists[rtk::CUT_WORDS];
+    int parent_lvl = -1;
     for (int l = cp.top; l >= level; --l) {
+        if (!cp.present[l]) continue;
         cur.assign(size_t(cp.tiles[l]) * rtk::CUT_WORDS, 0u);
         ca.lvl = l;
+        ca.parent_shift = parent_lvl < 0 ? 0 : parent_lvl - l;
+        parent_lvl = l;
         ca.cap = cut_cap(l, cp);
         ca.tiles_x = cp.tiles_x[l];
         ca.n_tiles = (int32_t)cp.tiles[l];
@@ -1612,7 +1652,7 @@ int rt_last_cuts(rt_ctx* c, int level, uint32_t* words, int64_t capacity_words, 
     const CutPlan& cp = c->cut_plan;
     if (level_lo) *level_lo = cp.lo;
     if (level_top) *level_top = cp.top;
-    if (level < cp.lo || level > cp.top) return fail(RT_E_INVALID, "rt_last_cuts: no such level");
+    if (level < cp.lo || level > cp.top || !cp.present[level]) return fail(RT_E_INVALID, "rt_last_cuts: no such level");
     if (tiles_x) *tiles_x = cp.tiles_x[level];
     const int64_t n = cp.tiles[level] * rtk::CUT_WORDS;
     if (words) {

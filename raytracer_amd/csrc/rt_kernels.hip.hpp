@@ -795,6 +795,7 @@ struct PacketArgs {
     // levels cut_lo .. tile_log2 are present (cut_lo < 0: no cuts, every batch walks from the root)
     const uint32_t* cut_lvl[5];
     int32_t cut_tx[5];
+    int32_t cut_eff[5];  // level whose cuts cut_lvl[l] / cut_tx[l] are: l, or the next coarser one that was made
     int32_t cut_lo;
 };
 
@@ -915,8 +916,9 @@ struct CutArgs {
     int32_t W, rows, row0;
     int32_t lvl;               // blocks of (1 << lvl)^2 pixels
     int32_t tiles_x, n_tiles;  // of this level
-    const uint32_t* parent;    // cuts of level lvl + 1 (parent_tiles_x blocks per row), or null: start at the root
+    const uint32_t* parent;    // cuts of level lvl + parent_shift (parent_tiles_x blocks per row), or null: start at the root
     int32_t parent_tiles_x;
+    int32_t parent_shift;
     double mag;                // bound of the magnitudes any sample position of the image is computed from
     int32_t cap;               // entries a list of this level may hold (<= CUT_CAP)
     uint32_t* cuts;            // n_tiles * CUT_WORDS
@@ -1008,7 +1010,7 @@ __host__ __device__ inline void cut_refine(const CutArgs& a, const int tile, uin
     int sp = 0;  // entries waiting, the next one on top
     const uint32_t* par = nullptr;
     if (a.parent) {
-        par = a.parent + ((size_t)(tiy >> 1) * a.parent_tiles_x + (tix >> 1)) * CUT_WORDS;
+        par = a.parent + ((size_t)(tiy >> a.parent_shift) * a.parent_tiles_x + (tix >> a.parent_shift)) * CUT_WORDS;
         if (!(par[0] & CUT_VALID)) par = nullptr;
     }
     if (par) {
@@ -1216,16 +1218,18 @@ __global__ __launch_bounds__(NT, 8) void render_packet_kernel(const PacketArgs a
             lvl = max(lvl, a.cut_lo);
             if (pxf < a.W && pyf < a.rows && pxl < a.W && pyl < a.rows) {
                 unsigned long long base_ptr;
-                uint32_t ctx;
+                uint32_t ctx, eff;
                 const auto kseg = __builtin_amdgcn_kernarg_segment_ptr();
                 const uint32_t o1 = (uint32_t)offsetof(PacketArgs, cut_lvl) + 8u * (uint32_t)lvl;
                 const uint32_t o2 = (uint32_t)offsetof(PacketArgs, cut_tx) + 4u * (uint32_t)lvl;
-                asm volatile("s_load_dwordx2 %0, %2, %3\n\ts_load_dword %1, %2, %4\n\ts_waitcnt lgkmcnt(0)"
-                             : "=&s"(base_ptr), "=&s"(ctx)
-                             : "s"(kseg), "s"(o1), "s"(o2)
-                             : "memory");
+                const uint32_t o3 = (uint32_t)offsetof(PacketArgs, cut_eff) + 4u * (uint32_t)lvl;
+                asm volatile(
+                    "s_load_dwordx2 %0, %3, %4\n\ts_load_dword %1, %3, %5\n\ts_load_dword %2, %3, %6\n\ts_waitcnt lgkmcnt(0)"
+                    : "=&s"(base_ptr), "=&s"(ctx), "=&s"(eff)
+                    : "s"(kseg), "s"(o1), "s"(o2), "s"(o3)
+                    : "memory");
                 const uint32_t* const cp = reinterpret_cast<const uint32_t*>(base_ptr) +
-                                           ((size_t)(pyf >> lvl) * ctx + (size_t)(pxf >> lvl)) * CUT_WORDS;
+                                           ((size_t)(pyf >> eff) * ctx + (size_t)(pxf >> eff)) * CUT_WORDS;
                 if (lane < CUT_WORDS) q.vcut = cp[lane];
             }
         }

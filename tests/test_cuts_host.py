@@ -154,7 +154,9 @@ def two_meshes():
 
 
 @pytest.mark.parametrize("level", [1, 2, 3])
-def test_cut_walk_equals_root_walk_two_meshes_rotated_camera(level):
+def test_cut_walk_equals_root_walk_two_meshes_rotated_camera(level, monkeypatch):
+    if level == 2:
+        monkeypatch.setenv("RT_CUT_STEP", "1")  # every level is made (default: the top, every second one, the finest)
     coords, colors = two_meshes()
     H, W = 20, 32
     for ci, cam in enumerate([meshgen.camera_arrays(W, H),
