@@ -214,7 +214,7 @@ def test_cut_walk_camera_inside_the_cloud_and_far_from_the_origin():
     c, k = meshgen.random_soup(600, seed=21, extent=4.0, z_range=(-4.0, 4.0))
     H, W = 16, 16
     cams = [meshgen.camera_arrays(W, H, center=(0.2, -0.1, 0.3), target=(1.0, 0.5, -1.0), fov=100),
-            meshgen.camera_arrays(W, H, center=(0.0, 0.0, 0.0), target=(0.0, 1.0, 0.0), fov=60)]
+            meshgen.camera_arrays(W, H, center=(0.0, 0.0, 0.0), target=(0.2, 1.0, -0.3), fov=60)]
     for ci, cam in enumerate(cams):
         check_scene([c], [k], cam, H, W, 64, 1, seed=30 + ci)
     off = np.array([1.0e4, -2.0e4, 5.0e3])
