@@ -1039,6 +1039,72 @@ struct PacketBuffers {
     uint32_t* cuts;  // plan_cuts(...).total_words words for the cut levels, or null: every batch walks from the root
 };
 
+// What a render kernel is told about the cuts of its launch (rtk::PacketArgs / rtk32::Packet32Args).
+struct CutTables {
+    const uint32_t* lvl[rtk::CUT_MAX_LEVELS] = {};
+    int32_t tx[rtk::CUT_MAX_LEVELS] = {};
+    int32_t eff[rtk::CUT_MAX_LEVELS] = {0, 1, 2, 3, 4};
+    int32_t lo = -1;  // < 0: no cuts, every batch walks from the root
+};
+
+// The cut kernels of one launch (cut_level_kernel, level after level) on c->stream, from the camera-relative boxes
+// the prep kernels have written.  `allowed`: not with visit counters (they count the reference's visit rule), not
+// without min <= max boxes and tame coordinates (the cut's argument rests on the NaN-free slab test).  Allocates
+// nothing; `cuts` = plan_cuts(...).total_words words, or null.
+int make_cuts(rt_ctx* c, const rt_render_params* p, int tile_log2, const rtk::FrameParams& fp, const rt::DevNode* cam_nodes,
+              const rt::DevNode* cam_tlas, uint32_t* cuts, bool allowed, CutTables& out) {
+    out = CutTables{};
+    const int W = p->image_width, spp = p->samples, rows = p->row_end - p->row_begin;
+    const bool no_cut = std::getenv("RT_NO_CUT") != nullptr;  // (comparison / test knob, read per launch)
+    // The cut kernels are chains of dependent steps (~0.3 ms however small the image) and save about a third of the
+    // traversal: they pay from a few ms of traversal on.  Measured break-even: ~30 M rays (1024 x 576 x 50).
+    const char* mr = std::getenv("RT_CUT_MIN_RAYS");  // (tuning knob)
+    const double min_rays = mr ? std::atof(mr) : 64e6;
+    if (!cuts || !allowed || no_cut || double(rows) * W * spp < min_rays) return RT_OK;
+    const CutPlan cp = plan_cuts(W, rows, spp, tile_log2);
+    rtk::CutArgs ca;
+    ca.nodes = cam_nodes;
+    ca.tlas = cam_tlas;
+    ca.slot_root = c->slot_root.p;
+    ca.fp = fp;
+    ca.W = W;
+    ca.rows = rows;
+    ca.row0 = p->row_begin;
+    ca.parent = nullptr;
+    ca.parent_tiles_x = 0;
+    ca.mag = rtk::cut_magnitude(ca.fp, W, p->row_begin, rows);
+    int parent_lvl = -1;
+    for (int l = cp.top; l >= cp.lo; --l) {  // each level from its parent's cuts, the top one from the root
+        if (!cp.present[l]) continue;
+        ca.lvl = l;
+        ca.parent_shift = parent_lvl < 0 ? 0 : parent_lvl - l;
+        parent_lvl = l;
+        ca.cap = cut_cap(l, cp);
+        ca.tiles_x = cp.tiles_x[l];
+        ca.n_tiles = (int32_t)cp.tiles[l];
+        ca.cuts = cuts + cp.offset_words[l];
+        const int64_t patches = int64_t((cp.tiles_x[l] + 7) / 8) * ((cp.tiles[l] / cp.tiles_x[l] + 7) / 8);
+        const int per_wg = rtk::CUT_THREADS / 64;  // one 8 x 8 patch of blocks per wave
+        hipLaunchKernelGGL(rtk::cut_level_kernel, dim3((unsigned)((patches + per_wg - 1) / per_wg)), dim3(rtk::CUT_THREADS),
+                           0, c->stream, ca);
+        ca.parent = ca.cuts;
+        ca.parent_tiles_x = ca.tiles_x;
+    }
+    HIP_TRY(hipGetLastError());
+    // what a batch finds at level l: that level's cuts, or those of the next coarser level that was made
+    for (int l = cp.lo; l <= tile_log2 && l < rtk::CUT_MAX_LEVELS; ++l) {
+        int e = l;
+        while (!cp.present[e]) ++e;  // the top level (>= tile_log2) always is
+        out.lvl[l] = cuts + cp.offset_words[e];
+        out.tx[l] = cp.tiles_x[e];
+        out.eff[l] = e;
+    }
+    out.lo = cp.lo;
+    HIP_TRY(hipEventRecord(c->cuts_done, c->stream));
+    c->cuts_done_pending = true;
+    return RT_OK;
+}
+
 // prep kernels + render_packet_kernel on c->stream, bracketed by the context's timing events.  Allocates nothing.
 int launch_packet(rt_ctx* c, const rt_render_params* p, int tile_log2, int tiles_x, int64_t n_tiles, const PacketBuffers& pb,
                   bool* cuts_made = nullptr) {
@@ -1089,65 +1155,15 @@ int launch_packet(rt_ctx* c, const rt_render_params* p, int tile_log2, int tiles
     if (const char* e = std::getenv("RT_INTERLEAVE")) a.interleave = std::atoi(e);  // experiment: 0, 1, 2, 4, ...
     if (a.interleave && ((a.interleave & (a.interleave - 1)) || a.interleave > ((1 << (2 * tile_log2)) >> 2))) a.interleave = 0;
     a.fast_ok = (c->max_abs_coord + std::fabs(ox) + std::fabs(oy) + std::fabs(oz)) < 1e100 ? 2 : 0;
-    // Tile cuts (tile_cut_kernel): the upper tree levels classified once per tile.  Not with visit counters (they
-    // count the reference's visit rule), not without the octant-specialised slab test the cut's argument rests on.
-    const bool no_cut = std::getenv("RT_NO_CUT") != nullptr;  // (comparison / test knob, read per launch)
-    a.cut_lo = -1;
+    CutTables ct;
+    int rc = make_cuts(c, p, tile_log2, a.fpv, pb.cam_nodes, pb.cam_tlas, pb.cuts, !count && a.fast_ok == 2, ct);
+    if (rc) return rc;
     for (int l = 0; l < rtk::CUT_MAX_LEVELS; ++l) {
-        a.cut_lvl[l] = nullptr;
-        a.cut_tx[l] = 0;
-        a.cut_eff[l] = l;
+        a.cut_lvl[l] = ct.lvl[l];
+        a.cut_tx[l] = ct.tx[l];
+        a.cut_eff[l] = ct.eff[l];
     }
-    // The cut kernels are chains of dependent steps (~0.3 ms however small the image) and save about a third of the
-    // traversal: they pay from a few ms of traversal on.  Measured break-even: ~30 M rays (1024 x 576 x 50).
-    const char* mr = std::getenv("RT_CUT_MIN_RAYS");  // (tuning knob)
-    const double min_rays = mr ? std::atof(mr) : 64e6;
-    if (pb.cuts && !count && a.fast_ok == 2 && !no_cut && double(rows) * W * spp >= min_rays) {
-        const CutPlan cp = plan_cuts(W, rows, spp, tile_log2);
-        rtk::CutArgs ca;
-        ca.nodes = pb.cam_nodes;
-        ca.tlas = pb.cam_tlas;
-        ca.slot_root = c->slot_root.p;
-        ca.fp = a.fpv;
-        ca.W = W;
-        ca.rows = rows;
-        ca.row0 = p->row_begin;
-        ca.parent = nullptr;
-        ca.parent_tiles_x = 0;
-        ca.mag = rtk::cut_magnitude(ca.fp, W, p->row_begin, rows);
-        int parent_lvl = -1;
-        for (int l = cp.top; l >= cp.lo; --l) {  // each level from its parent's cuts, the top one from the root
-            if (!cp.present[l]) continue;
-            ca.lvl = l;
-            ca.parent_shift = parent_lvl < 0 ? 0 : parent_lvl - l;
-            parent_lvl = l;
-            ca.cap = cut_cap(l, cp);
-            ca.tiles_x = cp.tiles_x[l];
-            ca.n_tiles = (int32_t)cp.tiles[l];
-            ca.cuts = pb.cuts + cp.offset_words[l];
-            const int64_t patches = int64_t((cp.tiles_x[l] + 7) / 8) * ((cp.tiles[l] / cp.tiles_x[l] + 7) / 8);
-            const int per_wg = rtk::CUT_THREADS / 64;  // one 8 x 8 patch of blocks per wave
-            hipLaunchKernelGGL(rtk::cut_level_kernel, dim3((unsigned)((patches + per_wg - 1) / per_wg)),
-                               dim3(rtk::CUT_THREADS), 0, c->stream, ca);
-            ca.parent = ca.cuts;
-            ca.parent_tiles_x = ca.tiles_x;
-        }
-        HIP_TRY(hipGetLastError());
-        // what a batch finds at level l: that level's cuts, or those of the next coarser level that was made
-        for (int l = cp.lo; l <= tile_log2 && l < rtk::CUT_MAX_LEVELS; ++l) {
-            int e = l;
-            while (!cp.present[e]) ++e;  // the top level (>= tile_log2) always is
-            if (e >= rtk::CUT_MAX_LEVELS + 27) break;
-            a.cut_lvl[l] = pb.cuts + cp.offset_words[e];
-            a.cut_tx[l] = cp.tiles_x[e];
-            a.cut_eff[l] = e;
-        }
-        a.cut_lo = cp.lo;
-        // the sampler's look-ahead kernels (next frame's jitter, own stream) may overlap the long traversal kernel,
-        // not these short latency-bound ones: they slow each other down by 2x
-        HIP_TRY(hipEventRecord(c->cuts_done, c->stream));
-        c->cuts_done_pending = true;
-    }
+    a.cut_lo = ct.lo;
     if (cuts_made) *cuts_made = a.cut_lo >= 0;
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     if (count && a.pair64)
@@ -1302,7 +1318,30 @@ int render_impl(rt_ctx* c, const rt_render_params* p, bool pipelined) {
         for (int i = 0; i < 6; ++i) h_frame_params.sp[i] = p->pixel_spacing[i];
         HIP_TRY(hipMemcpyAsync(frame_params.p, &h_frame_params, sizeof(rtk::FrameParams), hipMemcpyHostToDevice,
                                c->stream));
+        // cuts: made from the exact camera-relative boxes (the fp32 records share the node numbering)
+        CutTables ct;
+        {
+            const CutPlan cp = plan_cuts(W, rows, spp, tile_log2);
+            if ((rc = c->cam_nodes.ensure(c->n_nodes))) return rc;
+            if ((rc = c->cam_tlas.ensure(c->n_tlas))) return rc;
+            if ((rc = c->cuts.ensure(size_t(cp.total_words)))) return rc;
+            hipLaunchKernelGGL(rtk::prep_nodes_kernel, dim3((unsigned)((c->n_nodes + 255) / 256)), dim3(256), 0, c->stream,
+                               c->nodes.p, c->cam_nodes.p, (long long)c->n_nodes, ox, oy, oz);
+            hipLaunchKernelGGL(rtk::prep_nodes_kernel, dim3((unsigned)((c->n_tlas + 255) / 256)), dim3(256), 0, c->stream,
+                               c->tlas.p, c->cam_tlas.p, (long long)c->n_tlas, ox, oy, oz);
+            const bool tame = (c->max_abs_coord + std::fabs(ox) + std::fabs(oy) + std::fabs(oz)) < 1e30;
+            if ((rc = make_cuts(c, p, tile_log2, h_frame_params, c->cam_nodes.p, c->cam_tlas.p, c->cuts.p, !count && tame, ct)))
+                return rc;
+            c->cut_plan = cp;
+            c->cut_plan_valid = ct.lo >= 0;
+        }
         rtk32::Packet32Args a;
+        for (int l = 0; l < rtk::CUT_MAX_LEVELS; ++l) {
+            a.cut_lvl[l] = ct.lvl[l];
+            a.cut_tx[l] = ct.tx[l];
+            a.cut_eff[l] = ct.eff[l];
+        }
+        a.cut_lo = ct.lo;
         a.nodes = c->nodes32.p;
         a.tlas = c->tlas32.p;
         a.slot_root = c->slot_root.p;

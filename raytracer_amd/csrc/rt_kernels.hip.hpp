@@ -1091,6 +1091,56 @@ __global__ __launch_bounds__(CUT_THREADS) void cut_level_kernel(const CutArgs a)
     cut_refine(a, tiy * a.tiles_x + tix, s_stk + threadIdx.x, CUT_THREADS);
 }
 
+// ---- the render kernels' side of the cuts (shared by the f64 and the fp32 packet kernels) ----
+// The cut of the smallest aligned pixel block that holds a batch's pixels: m_first / m_last are the Morton indices
+// (within the tile) of its first and last ray's pixel -- an aligned block is an interval of Morton indices -- and
+// (pxf, pyf), (pxl, pyl) those pixels.  Lane i < CUT_WORDS returns word i of the block's record (lane 0 = header),
+// 0 when a pixel lies outside the image.  The level tables sit in the kernel arguments at the given offsets and are
+// read from the kernarg segment here (see karg_ptr).
+template <int OFF_LVL, int OFF_TX, int OFF_EFF>
+__device__ __forceinline__ uint32_t load_batch_cut(const int cut_lo, const int m_first, const int m_last, const int pxf,
+                                                   const int pyf, const int pxl, const int pyl, const int W,
+                                                   const int rows, const int lane) {
+    uint32_t v = 0u;
+    const uint32_t x = (uint32_t)(m_first ^ m_last);
+    int lvl = x ? ((31 - __builtin_clz(x)) >> 1) + 1 : 0;
+    lvl = max(lvl, cut_lo);
+    if (pxf < W && pyf < rows && pxl < W && pyl < rows) {
+        unsigned long long base_ptr;
+        uint32_t ctx, eff;
+        const auto kseg = __builtin_amdgcn_kernarg_segment_ptr();
+        const uint32_t o1 = (uint32_t)OFF_LVL + 8u * (uint32_t)lvl;
+        const uint32_t o2 = (uint32_t)OFF_TX + 4u * (uint32_t)lvl;
+        const uint32_t o3 = (uint32_t)OFF_EFF + 4u * (uint32_t)lvl;
+        asm volatile(
+            "s_load_dwordx2 %0, %3, %4\n\ts_load_dword %1, %3, %5\n\ts_load_dword %2, %3, %6\n\ts_waitcnt lgkmcnt(0)"
+            : "=&s"(base_ptr), "=&s"(ctx), "=&s"(eff)
+            : "s"(kseg), "s"(o1), "s"(o2), "s"(o3)
+            : "memory");
+        const uint32_t* const cp = reinterpret_cast<const uint32_t*>(base_ptr) +
+                                   ((size_t)(pyf >> eff) * ctx + (size_t)(pxf >> eff)) * CUT_WORDS;
+        if (lane < CUT_WORDS) v = cp[lane];
+    }
+    return v;
+}
+
+// Number of entries of the batch's cut, or -1: walk from the root.  The cut holds for rays through its block with
+// offsets in [-0.5, 0.5] whose direction signs are the ones it was computed for (caller-supplied offsets may be
+// anything); the caller adds that no lane is NaN-prone.
+__device__ __forceinline__ int batch_cut_entries(const uint32_t vcut, const unsigned long long amask,
+                                                 const unsigned long long ngx, const unsigned long long ngy,
+                                                 const unsigned long long ngz, const double jx, const double jy) {
+    const uint32_t cut_hdr = (uint32_t)__builtin_amdgcn_readfirstlane((int)vcut);
+    if (!(cut_hdr & CUT_VALID)) return -1;
+    const uint32_t kx = (cut_hdr >> 8) & 3u, ky = (cut_hdr >> 10) & 3u, kz = (cut_hdr >> 12) & 3u;
+    const bool sx_ok = kx == 2u || (kx == 1u ? ngx == amask : ngx == 0ull);
+    const bool sy_ok = ky == 2u || (ky == 1u ? ngy == amask : ngy == 0ull);
+    const bool sz_ok = kz == 2u || (kz == 1u ? ngz == amask : ngz == 0ull);
+    const bool in_range = __builtin_fabs(jx) <= 0.5 && __builtin_fabs(jy) <= 0.5;
+    if (sx_ok && sy_ok && sz_ok && (__builtin_amdgcn_ballot_w64(!in_range) & amask) == 0ull) return (int)(cut_hdr & 0xffu);
+    return -1;
+}
+
 // ---- the compiler's fp64 division, for operands that need no scaling (see render_packet_kernel) ----
 __device__ __forceinline__ uint32_t hi_abs(const double x) {
     return (uint32_t)(__builtin_bit_cast(unsigned long long, x) >> 32) & 0x7fffffffu;
@@ -1204,8 +1254,6 @@ __global__ __launch_bounds__(NT, 8) void render_packet_kernel(const PacketArgs a
         // streamed once: non-temporal, so the 16 B/sample stream does not displace tree nodes in L2
         if (q.active)
             q.jit = __builtin_nontemporal_load(karg_ptr<const d2, offsetof(PacketArgs, jitter)>() + q.sidx);
-        // the cut of the smallest aligned pixel block that holds the batch's pixels (Morton indices m of its first
-        // and last ray: an aligned block is an interval of Morton indices)
         q.vcut = 0u;
         if (a.cut_lo >= 0) {
             const int last = min(63, n_rays - 1 - base);
@@ -1213,25 +1261,8 @@ __global__ __launch_bounds__(NT, 8) void render_packet_kernel(const PacketArgs a
             const int pxf = __builtin_amdgcn_readfirstlane(q.px), pyf = __builtin_amdgcn_readfirstlane(q.py);
             const int pxl = P64 ? pxf : __builtin_amdgcn_readlane(q.px, last);
             const int pyl = P64 ? pyf : __builtin_amdgcn_readlane(q.py, last);
-            const uint32_t x = (uint32_t)(mf ^ ml2);
-            int lvl = x ? ((31 - __builtin_clz(x)) >> 1) + 1 : 0;
-            lvl = max(lvl, a.cut_lo);
-            if (pxf < a.W && pyf < a.rows && pxl < a.W && pyl < a.rows) {
-                unsigned long long base_ptr;
-                uint32_t ctx, eff;
-                const auto kseg = __builtin_amdgcn_kernarg_segment_ptr();
-                const uint32_t o1 = (uint32_t)offsetof(PacketArgs, cut_lvl) + 8u * (uint32_t)lvl;
-                const uint32_t o2 = (uint32_t)offsetof(PacketArgs, cut_tx) + 4u * (uint32_t)lvl;
-                const uint32_t o3 = (uint32_t)offsetof(PacketArgs, cut_eff) + 4u * (uint32_t)lvl;
-                asm volatile(
-                    "s_load_dwordx2 %0, %3, %4\n\ts_load_dword %1, %3, %5\n\ts_load_dword %2, %3, %6\n\ts_waitcnt lgkmcnt(0)"
-                    : "=&s"(base_ptr), "=&s"(ctx), "=&s"(eff)
-                    : "s"(kseg), "s"(o1), "s"(o2), "s"(o3)
-                    : "memory");
-                const uint32_t* const cp = reinterpret_cast<const uint32_t*>(base_ptr) +
-                                           ((size_t)(pyf >> eff) * ctx + (size_t)(pxf >> eff)) * CUT_WORDS;
-                if (lane < CUT_WORDS) q.vcut = cp[lane];
-            }
+            q.vcut = load_batch_cut<offsetof(PacketArgs, cut_lvl), offsetof(PacketArgs, cut_tx), offsetof(PacketArgs, cut_eff)>(
+                a.cut_lo, mf, ml2, pxf, pyf, pxl, pyl, a.W, a.rows, lane);
         }
         return q;
     };
@@ -1329,19 +1360,7 @@ __global__ __launch_bounds__(NT, 8) void render_packet_kernel(const PacketArgs a
             const unsigned long long ngz = __builtin_amdgcn_ballot_w64(iz < 0.0) & amask;
             const bool uni = (ngx == 0ull || ngx == amask) && (ngy == 0ull || ngy == amask) &&
                              (ngz == 0ull || ngz == amask) && a.fast_ok == 2;
-            // The batch's cut holds for rays through its block with offsets in [-0.5, 0.5] whose direction signs are
-            // the ones it was computed for, and no NaN-prone lane (caller-supplied offsets may be anything).
-            int n_ent = -1;
-            const uint32_t cut_hdr = (uint32_t)__builtin_amdgcn_readfirstlane((int)cs.vcut);
-            if (cut_hdr & CUT_VALID) {
-                const uint32_t kx = (cut_hdr >> 8) & 3u, ky = (cut_hdr >> 10) & 3u, kz = (cut_hdr >> 12) & 3u;
-                const bool sx_ok = kx == 2u || (kx == 1u ? ngx == amask : ngx == 0ull);
-                const bool sy_ok = ky == 2u || (ky == 1u ? ngy == amask : ngy == 0ull);
-                const bool sz_ok = kz == 2u || (kz == 1u ? ngz == amask : ngz == 0ull);
-                const bool in_range = __builtin_fabs(cs.jit.x) <= 0.5 && __builtin_fabs(cs.jit.y) <= 0.5;
-                if (sx_ok && sy_ok && sz_ok && (__builtin_amdgcn_ballot_w64(!in_range) & amask) == 0ull)
-                    n_ent = (int)(cut_hdr & 0xffu);
-            }
+            const int n_ent = batch_cut_entries(cs.vcut, amask, ngx, ngy, ngz, cs.jit.x, cs.jit.y);
             if (__builtin_amdgcn_ballot_w64(risky) != 0ull) {
                 trace_packet<false, -1, COUNT>(a.sc, amask, dx, dy, dz, ix, iy, iz, wstk, h, wc, 0u, -1);
             } else if (uni) {

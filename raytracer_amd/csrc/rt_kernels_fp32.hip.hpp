@@ -146,6 +146,11 @@ struct Packet32Args {
     int32_t* hit_prim;
     double* hit_t;
     unsigned long long* counters;
+    // cuts, as in rtk::PacketArgs (made from the f64 camera-relative boxes: the node indices are the same)
+    const uint32_t* cut_lvl[5];
+    int32_t cut_tx[5];
+    int32_t cut_eff[5];
+    int32_t cut_lo;
 };
 
 struct Hit32 {
@@ -188,10 +193,17 @@ template <int OCT, bool COUNT>
 __device__ __forceinline__ void trace_packet32(const Packet32Args& sc, const unsigned long long valid_mask,
                                                const float dx, const float dy, const float dz, const float ix,
                                                const float iy, const float iz, uint4* wstk, Hit32& h,
-                                               rtk::WaveCounters& wc) {
+                                               rtk::WaveCounters& wc, const uint32_t vlist, int n_entries) {
     const f2 ixy = f2{ix, iy}, izx = f2{iz, ix}, iyz = f2{iy, iz};
     int sp = 0;
+    int ei = 1;  // entry list of the batch's cut, as in rtk::trace_packet (n_entries < 0: walk from the root)
     uint32_t cur = rt::DESC_TLAS;
+    if (n_entries < 0) {
+        n_entries = 0;
+    } else {
+        if (n_entries == 0) return;
+        cur = (uint32_t)__builtin_amdgcn_readlane((int)vlist, 1);
+    }
     unsigned long long inm = valid_mask;
     for (;;) {
         while ((cur & (rt::DESC_LEAF | rt::DESC_TLAS | rt::DESC_ROOT)) == 0u) {
@@ -267,6 +279,18 @@ __device__ __forceinline__ void trace_packet32(const Packet32Args& sc, const uns
                         }
                     }
                 }
+            } else if ((cur & rtk::CUT_NODE_ENTRY) == rtk::CUT_NODE_ENTRY) {
+                // entry of a cut: a BLAS node whose own box is tested per ray
+                const uint32_t ni = cur & 0x1FFFFFFFu;
+                cfptr q = (cfptr)(const void*)(sc.nodes + ni);
+                const uint32_t desc = ((rtk::cuptr)(const void*)(sc.nodes + ni))[6];
+                if (COUNT) wc.nodes += (unsigned)__builtin_popcountll(inm);
+                const unsigned long long hm = slab32<OCT>(q[0], q[1], q[2], q[3], q[4], q[5], ixy, izx, iyz) & inm;
+                if (hm != 0ull) {
+                    cur = desc;
+                    inm = hm;
+                    continue;
+                }
             } else if (cur & rt::DESC_TLAS) {
                 cfptr q = (cfptr)(const void*)(sc.tlas + (cur & 0x3FFFFFFFu));
                 const RT_CONST int32_t* qi = (const RT_CONST int32_t*)(const void*)(sc.tlas + (cur & 0x3FFFFFFFu));
@@ -297,7 +321,13 @@ __device__ __forceinline__ void trace_packet32(const Packet32Args& sc, const uns
                 }
             }
         }
-        if (sp == 0) break;
+        if (sp == 0) {
+            if (ei >= n_entries) break;
+            ++ei;
+            cur = (uint32_t)__builtin_amdgcn_readlane((int)vlist, ei);
+            inm = valid_mask;
+            continue;
+        }
         --sp;
         const uint4 e = wstk[sp];
         cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.x);
@@ -349,6 +379,7 @@ __global__ __launch_bounds__(NT, 8) void render_packet32_kernel(const Packet32Ar
         bool active;
         size_t sidx;
         rtk::d2 jit;
+        uint32_t vcut;  // the batch's cut: lane 0 = header, lanes 1.. = entries (0: none)
     };
     auto fetch = [&](const int base) {
         Slot q;
@@ -363,6 +394,15 @@ __global__ __launch_bounds__(NT, 8) void render_packet32_kernel(const Packet32Ar
         q.jit = rtk::d2{0.0, 0.0};
         // streamed once: non-temporal, so the 16 B/sample stream does not displace tree nodes in L2
         if (q.active) q.jit = __builtin_nontemporal_load(reinterpret_cast<const rtk::d2*>(a.jitter) + q.sidx);
+        q.vcut = 0u;
+        if (a.cut_lo >= 0) {
+            const int last = min(63, n_rays - 1 - base);
+            q.vcut = rtk::load_batch_cut<offsetof(Packet32Args, cut_lvl), offsetof(Packet32Args, cut_tx),
+                                         offsetof(Packet32Args, cut_eff)>(
+                a.cut_lo, __builtin_amdgcn_readfirstlane(m), __builtin_amdgcn_readlane(m, last),
+                __builtin_amdgcn_readfirstlane(q.px), __builtin_amdgcn_readfirstlane(q.py),
+                __builtin_amdgcn_readlane(q.px, last), __builtin_amdgcn_readlane(q.py, last), a.W, a.rows, lane);
+        }
         return q;
     };
     Slot nxt = fetch(0);
@@ -408,12 +448,18 @@ __global__ __launch_bounds__(NT, 8) void render_packet32_kernel(const Packet32Ar
             const unsigned long long ngy = __builtin_amdgcn_ballot_w64(iy < 0.0f) & amask;
             const unsigned long long ngz = __builtin_amdgcn_ballot_w64(iz < 0.0f) & amask;
             const bool uni = (ngx == 0ull || ngx == amask) && (ngy == 0ull || ngy == amask) && (ngz == 0ull || ngz == amask);
+            // the batch's cut (made for the exact f64 test; this path's boxes are those boxes rounded outward, so a
+            // ray the cut is sure about is one this path agrees on up to its own tolerance); not with infinite 1/d
+            const bool wild = active && !(__builtin_fabsf(ix) < 1e30f && __builtin_fabsf(iy) < 1e30f && __builtin_fabsf(iz) < 1e30f);
+            const int n_ent = __builtin_amdgcn_ballot_w64(wild) != 0ull
+                                  ? -1
+                                  : rtk::batch_cut_entries(cs.vcut, amask, ngx, ngy, ngz, cs.jit.x, cs.jit.y);
             if (uni) {
                 const int oct = (ngx != 0ull ? 1 : 0) | (ngy != 0ull ? 2 : 0) | (ngz != 0ull ? 4 : 0);
                 switch (oct) {
 #define RT_OCT32_CASE(O)                                                                    \
     case O:                                                                                 \
-        trace_packet32<O, COUNT>(a, amask, dx, dy, dz, ix, iy, iz, wstk, h, wc);            \
+        trace_packet32<O, COUNT>(a, amask, dx, dy, dz, ix, iy, iz, wstk, h, wc, cs.vcut, n_ent); \
         break;
                     RT_OCT32_CASE(0)
                     RT_OCT32_CASE(1)
@@ -426,7 +472,7 @@ __global__ __launch_bounds__(NT, 8) void render_packet32_kernel(const Packet32Ar
 #undef RT_OCT32_CASE
                 }
             } else {
-                trace_packet32<-1, COUNT>(a, amask, dx, dy, dz, ix, iy, iz, wstk, h, wc);
+                trace_packet32<-1, COUNT>(a, amask, dx, dy, dz, ix, iy, iz, wstk, h, wc, cs.vcut, n_ent);
             }
             if (COUNT && lane == 0) {
                 w_nodes += wc.nodes;
