@@ -187,8 +187,6 @@ struct rt_ctx {
     DevBuf<double> prev_intensity;
     DevBuf<uint8_t> prev_rgb;
     hipEvent_t out_done = nullptr, prev_out_done = nullptr;  // traversal kernel of the last / previous launch
-    hipEvent_t cuts_done = nullptr;  // the cut kernels of the last launch (the sampler's look-ahead waits for them)
-    bool cuts_done_pending = false;
     size_t n_nodes = 0, n_tlas = 0;
     double max_abs_coord = 0.0;  // largest |coordinate| of the uploaded scene (NaN/inf -> inf)
     int32_t stack_need = 1;
@@ -196,6 +194,8 @@ struct rt_ctx {
     // sampler
     uint32_t seed = 5489u;
     uint64_t pos = 0;            // position of the global stream, in 32-bit outputs
+    uint64_t state_pos = 0;      // position d_state belongs to (<= pos: a slot of several frames is consumed frame by
+                                 // frame without a jump per frame; sync_state() brings d_state up to pos when needed)
     DevBuf<uint32_t> d_tmp;      // scratch state for in-place jumps
     DevBuf<uint32_t> d_state;    // generator state preceding `pos` (624 raw words), device resident;
                                  // every sampler operation is ordered on rng_stream
@@ -210,6 +210,7 @@ struct rt_ctx {
         bool valid = false;
         uint64_t pos = 0;  // stream position the slot starts at
         int rows = 0, W = 0, spp = 0;
+        int frames = 1;    // consecutive launches of that shape the slot holds the pairs of (small frames: several)
         hipEvent_t done = nullptr, t0 = nullptr, t1 = nullptr;
         hipEvent_t read_done = nullptr;  // the traversal kernel that last read buf (refills wait for it)
         bool read_pending = false;
@@ -312,7 +313,7 @@ struct StreamPlan {
     uint64_t total_words = 0;  // rows*W*spp*4 (the last stream stops there)
 };
 
-StreamPlan plan_streams(int rows, int W, int spp) {
+StreamPlan plan_streams(int rows, int W, int spp, int frames = 1) {
     StreamPlan p;
     // One workgroup per stream.  Measured: a stream regenerates 624 words in ~1.2 us (a chain of dependent
     // LDS round trips), i.e. ~1.9 ns/word, and one jump costs ~1.2 us of the whole GPU.  The traversal kernel
@@ -320,7 +321,7 @@ StreamPlan plan_streams(int rows, int W, int spp) {
     // hides behind, whatever the frame size; more streams only add jump work.  Up to 256 streams (1024 for
     // very large frames, below), none shorter than 2^16 words (2^13 for the first 64); strides are whole
     // regenerations, not whole rows.
-    const uint64_t words = uint64_t(rows) * uint64_t(W) * uint64_t(spp) * 4u;
+    const uint64_t words = uint64_t(rows) * uint64_t(W) * uint64_t(spp) * 4u * uint64_t(frames);
     uint64_t target = std::min<uint64_t>(256, std::max<uint64_t>(1, words >> 16));
     // small frames are bound by the latency of one wave walking its stream: allow up to 64 shorter streams
     target = std::max<uint64_t>(target, std::min<uint64_t>(64, words >> 13));
@@ -414,15 +415,24 @@ int launch_jitter(rt_ctx* c, uint32_t* d_states, const StreamPlan& pl, double* d
     return RT_OK;
 }
 
-// Generate the jitter of one launch (rows x W x spp samples starting `ahead` words after the
-// context's current position) into slot `k`, entirely on rng_stream.
-int fill_slot(rt_ctx* c, int k, uint64_t ahead, int rows, int W, int spp) {
+// d_state := the generator state at c->pos (it may lag behind while a slot of several frames is consumed).
+int sync_state(rt_ctx* c) {
+    if (c->state_pos == c->pos) return RT_OK;
+    int rc = dev_jump(c, c->d_state.p, c->d_state.p, c->pos - c->state_pos);  // state_pos <= pos always
+    if (rc) return rc;
+    c->state_pos = c->pos;
+    return RT_OK;
+}
+
+// Generate the jitter of `frames` consecutive launches (rows x W x spp samples each, the first one starting `ahead`
+// words after the context's current position) into slot `k`, entirely on rng_stream.
+int fill_slot(rt_ctx* c, int k, uint64_t ahead, int rows, int W, int spp, int frames = 1) {
     rt_ctx::JitterSlot& sl = c->slot[k];
     sl.valid = false;
-    const size_t n_smp = size_t(rows) * size_t(W) * size_t(spp);
+    const size_t n_smp = size_t(rows) * size_t(W) * size_t(spp) * size_t(frames);
     int rc = sl.buf.ensure(n_smp * 2);
     if (rc) return rc;
-    const StreamPlan pl = plan_streams(rows, W, spp);
+    const StreamPlan pl = plan_streams(rows, W, spp, frames);
     if ((rc = sl.d_states.ensure(size_t(pl.n) * rt::MT_N))) return rc;
     if ((rc = sl.d_end.ensure(rt::MT_N))) return rc;
     const double t0 = now_ms();
@@ -448,7 +458,7 @@ int fill_slot(rt_ctx* c, int k, uint64_t ahead, int rows, int W, int spp) {
                            (unsigned long long)(pl.stride / 2), (unsigned long long)(pl.total_words / 2));
         HIP_TRY(hipGetLastError());
     } else {
-        if ((rc = dev_jump(c, c->d_state.p, sl.d_states.p, ahead))) return rc;
+        if ((rc = dev_jump(c, c->d_state.p, sl.d_states.p, ahead + (c->pos - c->state_pos)))) return rc;
         if ((rc = dev_jump(c, sl.d_states.p, sl.d_end.p, pl.total_words))) return rc;
         if ((rc = launch_jitter(c, sl.d_states.p, pl, sl.buf.p))) return rc;
     }
@@ -463,6 +473,7 @@ int fill_slot(rt_ctx* c, int k, uint64_t ahead, int rows, int W, int spp) {
     sl.rows = rows;
     sl.W = W;
     sl.spp = spp;
+    sl.frames = frames;
     sl.valid = true;
     return RT_OK;
 }
@@ -775,8 +786,7 @@ rt_ctx* rt_create(int device) {
         hipEventCreateWithFlags(&c->front_last_use, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->back_last_use, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->out_done, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->prev_out_done, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->cuts_done, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->prev_out_done, hipEventDisableTiming) != hipSuccess) {
         g_err = "rt_create: copy stream / events";
         return nullptr;
     }
@@ -885,7 +895,6 @@ void rt_destroy(rt_ctx* c) {
     c->back.colors.release();
     if (c->out_done) (void)hipEventDestroy(c->out_done);
     if (c->prev_out_done) (void)hipEventDestroy(c->prev_out_done);
-    if (c->cuts_done) (void)hipEventDestroy(c->cuts_done);
     c->prev_intensity.release();
     c->prev_rgb.release();
     if (c->front_last_use) (void)hipEventDestroy(c->front_last_use);
@@ -937,6 +946,7 @@ int rt_rng_seed(rt_ctx* c, uint32_t seed) {
     rt::mt_seed(c->h_seed_state, seed);
     HIP_TRY(hipMemcpyAsync(c->d_state.p, c->h_seed_state.w, sizeof(rt::MtState), hipMemcpyHostToDevice, c->rng_stream));
     c->pos = 0;
+    c->state_pos = 0;
     for (auto& sl : c->slot) sl.valid = sl.states_ok = false;  // slots belong to the old seed's stream
     c->have_last_start = false;
     return RT_OK;
@@ -949,7 +959,7 @@ int rt_rng_seek(rt_ctx* c, uint64_t word_position) {
     try {
         int rc;
         if (word_position > c->pos) {
-            if ((rc = dev_jump(c, c->d_state.p, c->d_state.p, word_position - c->pos))) return rc;
+            if ((rc = dev_jump(c, c->d_state.p, c->d_state.p, word_position - c->state_pos))) return rc;
         } else {
             HIP_TRY(hipStreamSynchronize(c->rng_stream));
             rt::mt_seed(c->h_seed_state, c->seed);
@@ -962,6 +972,7 @@ int rt_rng_seek(rt_ctx* c, uint64_t word_position) {
     }
     // slots prefetched relative to other positions stay valid: they are keyed by absolute position
     c->pos = word_position;
+    c->state_pos = word_position;
     return RT_OK;
 }
 
@@ -979,12 +990,14 @@ int rt_rng_jitter(rt_ctx* c, int64_t n, int n_streams, double* out_host) {
         int rc = c->jitter.ensure(size_t(n));
         if (rc) return rc;
         if ((rc = c->d_states.ensure(size_t(pl.n) * rt::MT_N))) return rc;
+        if ((rc = sync_state(c))) return rc;
         if ((rc = dev_jump(c, c->d_state.p, c->d_states.p, 0))) return rc;
         if ((rc = launch_jitter(c, c->d_states.p, pl, c->jitter.p))) return rc;
         if ((rc = dev_jump(c, c->d_state.p, c->d_state.p, pl.total_words))) return rc;
         HIP_TRY(hipMemcpyAsync(out_host, c->jitter.p, size_t(n) * sizeof(double), hipMemcpyDeviceToHost, c->rng_stream));
         HIP_TRY(hipStreamSynchronize(c->rng_stream));
         c->pos += pl.total_words;
+        c->state_pos = c->pos;
     } catch (const std::exception& e) {
         return fail(RT_E_INVALID, e.what());
     }
@@ -995,6 +1008,12 @@ int rt_rng_jitter(rt_ctx* c, int64_t n, int n_streams, double* out_host) {
 int rt_rng_state(rt_ctx* c, uint32_t* state624) {
     if (!c || !state624) return fail(RT_E_INVALID, "rt_rng_state: null argument");
     HIP_TRY(hipSetDevice(c->device));
+    try {
+        int rc = sync_state(c);
+        if (rc) return rc;
+    } catch (const std::exception& e) {
+        return fail(RT_E_INVALID, e.what());
+    }
     HIP_TRY(hipMemcpyAsync(state624, c->d_state.p, sizeof(rt::MtState), hipMemcpyDeviceToHost, c->rng_stream));
     HIP_TRY(hipStreamSynchronize(c->rng_stream));
     return RT_OK;
@@ -1038,6 +1057,28 @@ struct PacketBuffers {
     unsigned long long* counters;
     uint32_t* cuts;  // plan_cuts(...).total_words words for the cut levels, or null: every batch walks from the root
 };
+
+// Camera-relative node / TLAS / triangle records of a frame in one launch (tris_out = null: boxes only).
+void launch_prep(rt_ctx* c, rt::DevNode* cam_nodes, rt::DevNode* cam_tlas, rtk::CamTri* cam_tris, double ox, double oy,
+                 double oz) {
+    rtk::PrepArgs pa;
+    pa.nodes_in = c->nodes.p;
+    pa.nodes_out = cam_nodes;
+    pa.n_nodes = (long long)c->n_nodes;
+    pa.tlas_in = c->tlas.p;
+    pa.tlas_out = cam_tlas;
+    pa.n_tlas = (long long)c->n_tlas;
+    pa.tris = c->tris.p;
+    pa.tris_out = cam_tris;
+    pa.n_tris = cam_tris ? (long long)c->n_tris : 0;
+    pa.ox = ox;
+    pa.oy = oy;
+    pa.oz = oz;
+    pa.nb_nodes = (unsigned)((4 * c->n_nodes + 255) / 256);
+    pa.nb_tlas = (unsigned)((4 * c->n_tlas + 255) / 256);
+    const unsigned nb_tris = (unsigned)((pa.n_tris + 255) / 256);
+    hipLaunchKernelGGL(rtk::prep_frame_kernel, dim3(pa.nb_nodes + pa.nb_tlas + nb_tris), dim3(256), 0, c->stream, pa);
+}
 
 // What a render kernel is told about the cuts of its launch (rtk::PacketArgs / rtk32::Packet32Args).
 struct CutTables {
@@ -1100,8 +1141,6 @@ int make_cuts(rt_ctx* c, const rt_render_params* p, int tile_log2, const rtk::Fr
         out.eff[l] = e;
     }
     out.lo = cp.lo;
-    HIP_TRY(hipEventRecord(c->cuts_done, c->stream));
-    c->cuts_done_pending = true;
     return RT_OK;
 }
 
@@ -1111,12 +1150,7 @@ int launch_packet(rt_ctx* c, const rt_render_params* p, int tile_log2, int tiles
     const int W = p->image_width, spp = p->samples, rows = p->row_end - p->row_begin;
     const bool count = pb.counters != nullptr;
     const double ox = p->camera_center[0], oy = p->camera_center[1], oz = p->camera_center[2];
-    hipLaunchKernelGGL(rtk::prep_nodes_kernel, dim3((unsigned)((c->n_nodes + 255) / 256)), dim3(256), 0, c->stream,
-                       c->nodes.p, pb.cam_nodes, (long long)c->n_nodes, ox, oy, oz);
-    hipLaunchKernelGGL(rtk::prep_nodes_kernel, dim3((unsigned)((c->n_tlas + 255) / 256)), dim3(256), 0, c->stream,
-                       c->tlas.p, pb.cam_tlas, (long long)c->n_tlas, ox, oy, oz);
-    hipLaunchKernelGGL(rtk::prep_tris_kernel, dim3((unsigned)((c->n_tris + 255) / 256)), dim3(256), 0, c->stream,
-                       c->tris.p, pb.cam_tris, (long long)c->n_tris, ox, oy, oz);
+    launch_prep(c, pb.cam_nodes, pb.cam_tlas, pb.cam_tris, ox, oy, oz);
     HIP_TRY(hipGetLastError());
     rtk::PacketArgs a;
     a.sc.nodes = pb.cam_nodes;
@@ -1209,7 +1243,10 @@ int render_impl(rt_ctx* c, const rt_render_params* p, bool pipelined) {
         int trc = resolve_kernel_ms(c);
         if (trc) return trc;
     }
-    HIP_TRY(hipStreamSynchronize(c->rng_stream));
+    // the other samplers write slot 0's buffer on the traversal stream: no look-ahead fill may be using it.  (MT19937
+    // launches need no such wait: everything they touch of the sampler is ordered on rng_stream or guarded by the
+    // slots' events, and a fill of several frames must not hold up the frames the slot in use still serves.)
+    if (p->sampler != RT_SAMPLER_MT19937) HIP_TRY(hipStreamSynchronize(c->rng_stream));
 
     int rc;
     // the previous launch's frame moves to prev_* (its kernel may still be writing it: only the
@@ -1236,6 +1273,7 @@ int render_impl(rt_ctx* c, const rt_render_params* p, bool pipelined) {
 
     // ---- jitter ----
     int use = 0;
+    int slot_frame = 0;  // which of the slot's frames this launch reads
     const uint64_t start_pos = c->pos;
     if (p->sampler == RT_SAMPLER_EXPLICIT) {
         use = 0;
@@ -1253,35 +1291,47 @@ int render_impl(rt_ctx* c, const rt_render_params* p, bool pipelined) {
                            c->slot[0].buf.p, (unsigned long long)n_smp, (unsigned long long)(c->pos / 4u), c->seed, 0u);
         HIP_TRY(hipGetLastError());
         try {  // the MT19937 state follows the position, so the samplers can be mixed within one stream
+            if ((rc = sync_state(c))) return rc;
             if ((rc = dev_jump(c, c->d_state.p, c->d_state.p, uint64_t(n_smp) * 4u))) return rc;
         } catch (const std::exception& e) {
             return fail(RT_E_INVALID, std::string("rt_render: sampler: ") + e.what());
         }
         c->pos += uint64_t(n_smp) * 4u;
+        c->state_pos = c->pos;
     } else {
         try {
             use = -1;
+            const uint64_t fw = uint64_t(n_smp) * 4u;
             for (int k = 0; k < 2; ++k) {
                 const auto& sl = c->slot[k];
-                if (sl.valid && sl.pos == c->pos && sl.rows == rows && sl.W == W && sl.spp == spp) use = k;
+                if (sl.valid && sl.rows == rows && sl.W == W && sl.spp == spp && c->pos >= sl.pos &&
+                    (c->pos - sl.pos) % fw == 0 && (c->pos - sl.pos) / fw < uint64_t(sl.frames)) {
+                    use = k;
+                    slot_frame = (int)((c->pos - sl.pos) / fw);
+                }
             }
             if (use < 0) {
                 use = 1 - c->last_slot;
+                slot_frame = 0;
                 if ((rc = fill_slot(c, use, 0, rows, W, spp))) return rc;
                 c->stats.host_jump_ms = c->slot[use].host_ms;
             }
             HIP_TRY(hipStreamWaitEvent(c->stream, c->slot[use].done, 0));
             c->jitter_timed = true;
-            HIP_TRY(hipMemcpyAsync(c->d_state.p, c->slot[use].d_end.p, sizeof(rt::MtState), hipMemcpyDeviceToDevice,
-                                   c->rng_stream));
-            c->pos += uint64_t(n_smp) * 4u;
-            c->slot[use].valid = false;  // consumed
+            c->pos += fw;
+            if (slot_frame == c->slot[use].frames - 1) {
+                // the slot's last frame: its end state is the generator state at the new position
+                HIP_TRY(hipMemcpyAsync(c->d_state.p, c->slot[use].d_end.p, sizeof(rt::MtState), hipMemcpyDeviceToDevice,
+                                       c->rng_stream));
+                c->state_pos = c->pos;
+                c->slot[use].valid = false;  // consumed
+            }  // else d_state stays behind (state_pos): nothing needs it while the slot serves the frames
             c->last_slot = use;
         } catch (const std::exception& e) {
             return fail(RT_E_INVALID, std::string("rt_render: sampler: ") + e.what());
         }
     }
-    const double* d_jitter = c->slot[use].buf.p;
+    const double* d_jitter = c->slot[use].buf.p + size_t(slot_frame) * n_smp * 2;
 
     // ---- traversal ----
     // the packet kernels address nodes with a 32-bit scalar byte offset: node array < 4 GB (6.7e7 nodes)
@@ -1325,10 +1375,7 @@ int render_impl(rt_ctx* c, const rt_render_params* p, bool pipelined) {
             if ((rc = c->cam_nodes.ensure(c->n_nodes))) return rc;
             if ((rc = c->cam_tlas.ensure(c->n_tlas))) return rc;
             if ((rc = c->cuts.ensure(size_t(cp.total_words)))) return rc;
-            hipLaunchKernelGGL(rtk::prep_nodes_kernel, dim3((unsigned)((c->n_nodes + 255) / 256)), dim3(256), 0, c->stream,
-                               c->nodes.p, c->cam_nodes.p, (long long)c->n_nodes, ox, oy, oz);
-            hipLaunchKernelGGL(rtk::prep_nodes_kernel, dim3((unsigned)((c->n_tlas + 255) / 256)), dim3(256), 0, c->stream,
-                               c->tlas.p, c->cam_tlas.p, (long long)c->n_tlas, ox, oy, oz);
+            launch_prep(c, c->cam_nodes.p, c->cam_tlas.p, nullptr, ox, oy, oz);
             const bool tame = (c->max_abs_coord + std::fabs(ox) + std::fabs(oy) + std::fabs(oz)) < 1e30;
             if ((rc = make_cuts(c, p, tile_log2, h_frame_params, c->cam_nodes.p, c->cam_tlas.p, c->cuts.p, !count && tame, ct)))
                 return rc;
@@ -1448,21 +1495,32 @@ int render_impl(rt_ctx* c, const rt_render_params* p, bool pipelined) {
     // other slot.  A wrong guess costs nothing but the wasted work.
     if (p->sampler == RT_SAMPLER_MT19937 && !std::getenv("RT_NO_LOOKAHEAD")) {
         try {
+            const uint64_t fw = uint64_t(n_smp) * 4u;
             uint64_t next = c->pos;
             if (c->have_last_start && start_pos > c->last_start) {
                 const uint64_t delta = start_pos - c->last_start;
-                if (delta >= uint64_t(n_smp) * 4u) next = start_pos + delta;
+                if (delta >= fw) next = start_pos + delta;
+            }
+            // Small frames: a slot holds several consecutive frames (one set of jumps and one sampler launch per
+            // group instead of per frame -- the jumps alone take as long as such a frame's traversal), and the group
+            // after the one in use is generated while the first of its frames renders.
+            int group = 1;
+            if (next == c->pos && !std::getenv("RT_NO_FRAME_GROUPS"))
+                group = (int)std::max<uint64_t>(1, std::min<uint64_t>(16, (uint64_t(1) << 25) / std::max<size_t>(n_smp, 1)));
+            const rt_ctx::JitterSlot& cur_sl = c->slot[use];
+            uint64_t target = next;
+            if (cur_sl.valid && next == c->pos) target = cur_sl.pos + uint64_t(cur_sl.frames) * fw;  // frames left in it
+            bool covered = false;
+            for (int k = 0; k < 2; ++k) {
+                const auto& sl = c->slot[k];
+                if (sl.valid && sl.rows == rows && sl.W == W && sl.spp == spp && target >= sl.pos &&
+                    (target - sl.pos) % fw == 0 && (target - sl.pos) / fw < uint64_t(sl.frames))
+                    covered = true;
             }
             const int other = 1 - use;
-            // (measured: making the look-ahead wait for the cut kernels halves their time -- both are latency-bound
-            // and slow each other down -- but the sampler then overlaps the traversal kernel for longer, which is
-            // bound by the same VALU issue slots: 27.3 instead of 26.4 ms per 4096^2 x 64 frame.  RT_LOOKAHEAD_AFTER_CUTS=1)
-            if (c->cuts_done_pending && std::getenv("RT_LOOKAHEAD_AFTER_CUTS"))
-                HIP_TRY(hipStreamWaitEvent(c->rng_stream, c->cuts_done, 0));
-            c->cuts_done_pending = false;
-            // slot `other` was last read by the previous call's kernel: fill_slot makes rng_stream wait
+            // slot `other` was last read by an earlier call's kernel: fill_slot makes rng_stream wait
             // for it (read_done); the slot's own jitter kernel is ordered on rng_stream.
-            if ((rc = fill_slot(c, other, next - c->pos, rows, W, spp))) return rc;
+            if (!covered && (rc = fill_slot(c, other, target - c->pos, rows, W, spp, group))) return rc;
         } catch (const std::exception&) {
             c->slot[1 - use].valid = false;
         }
@@ -1633,7 +1691,7 @@ int rt_tile_cuts_host(const rt_scene* scene, const rt_render_params* p, int leve
     if (cp.tiles[level] > 0x7fffffff) return fail(RT_E_LIMIT, "rt_tile_cuts_host: too many blocks");
     if (!words) return (int)cp.tiles[level];
     if (capacity_words < cp.tiles[level] * rtk::CUT_WORDS) return fail(RT_E_INVALID, "rt_tile_cuts_host: buffer too small");
-    // camera-relative boxes, as prep_nodes_kernel computes them
+    // camera-relative boxes, as prep_frame_kernel computes them
     auto relative = [&](const rt::DevNode* in, size_t n) {
         std::vector<rt::DevNode> out(in, in + n);
         for (auto& v : out)

@@ -1,7 +1,7 @@
 // rt_kernels.hip.hpp -- gfx950 device code of the render hot path (included by rt_api.hip).
 //
 // Kernels
-//   prep_nodes_kernel / prep_tris_kernel   per-frame camera-relative records (everything that depends
+//   prep_frame_kernel   per-frame camera-relative records (everything that depends
 //                      only on the camera centre, computed once per frame with the reference's operations)
 //   render_packet_kernel   THE hot kernel: ray generation + wave-packet TLAS/BLAS traversal on the scalar
 //                      unit + Moller-Trumbore + shading + in-order sample accumulation + luma/quantise
@@ -418,44 +418,72 @@ struct alignas(128) CamTri {
 };
 static_assert(sizeof(CamTri) == 128, "camera-relative triangle record must be 128 bytes");
 
-__global__ __launch_bounds__(256) void prep_nodes_kernel(const rt::DevNode* __restrict__ in, rt::DevNode* __restrict__ out,
-                                                         const long long n, const double ox, const double oy,
-                                                         const double oz) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    rt::DevNode v = in[i];
-    v.mn[0] = v.mn[0] - ox;
-    v.mn[1] = v.mn[1] - oy;
-    v.mn[2] = v.mn[2] - oz;
-    v.mx[0] = v.mx[0] - ox;
-    v.mx[1] = v.mx[1] - oy;
-    v.mx[2] = v.mx[2] - oz;
-    out[i] = v;
+// The three prep passes of a frame in ONE launch (small frames are bound by the number of launches): blocks
+// [0, nb_nodes) do the BLAS nodes, the next nb_tlas the TLAS nodes, the rest the triangles.  A node is handled by
+// four neighbouring lanes, 16 bytes each (coalesced; a thread per 64-byte record reaches a quarter of the
+// bandwidth): lanes 0..2 subtract the camera from two box coordinates, lane 3 copies the links.
+struct PrepArgs {
+    const rt::DevNode* nodes_in;
+    rt::DevNode* nodes_out;
+    long long n_nodes;
+    const rt::DevNode* tlas_in;
+    rt::DevNode* tlas_out;
+    long long n_tlas;
+    const double* tris;
+    CamTri* tris_out;
+    long long n_tris;
+    double ox, oy, oz;
+    unsigned nb_nodes, nb_tlas;  // blocks of 256 threads of the first two parts
+};
+
+__device__ __forceinline__ void prep_node_quarter(const rt::DevNode* __restrict__ in, rt::DevNode* __restrict__ out,
+                                                  const long long n, const long long t, const double ox, const double oy,
+                                                  const double oz) {
+    if (t >= 4 * n) return;
+    const int q = (int)(t & 3);
+    d2 v = reinterpret_cast<const d2*>(in)[t];
+    // record layout: mn0 mn1 | mn2 mx0 | mx1 mx2 | links
+    if (q == 0) {
+        v.x = v.x - ox;
+        v.y = v.y - oy;
+    } else if (q == 1) {
+        v.x = v.x - oz;
+        v.y = v.y - ox;
+    } else if (q == 2) {
+        v.x = v.x - oy;
+        v.y = v.y - oz;
+    }
+    reinterpret_cast<d2*>(out)[t] = v;
 }
 
-__global__ __launch_bounds__(256) void prep_tris_kernel(const double* __restrict__ tris, CamTri* __restrict__ out,
-                                                        const long long n, const double ox, const double oy,
-                                                        const double oz) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const double* tp = tris + (size_t)i * 9;
-    const double v0x = tp[0], v0y = tp[1], v0z = tp[2];
-    CamTri c;
-    c.e0[0] = tp[3] - v0x;
-    c.e0[1] = tp[4] - v0y;
-    c.e0[2] = tp[5] - v0z;
-    c.e2[0] = tp[6] - v0x;
-    c.e2[1] = tp[7] - v0y;
-    c.e2[2] = tp[8] - v0z;
-    c.tv[0] = ox - v0x;
-    c.tv[1] = oy - v0y;
-    c.tv[2] = oz - v0z;
-    c.q[0] = c.tv[1] * c.e0[2] - c.tv[2] * c.e0[1];
-    c.q[1] = c.tv[2] * c.e0[0] - c.tv[0] * c.e0[2];
-    c.q[2] = c.tv[0] * c.e0[1] - c.tv[1] * c.e0[0];
-    c.tnum = (c.e2[0] * c.q[0] + c.e2[1] * c.q[1]) + c.e2[2] * c.q[2];
-    c.pad[0] = c.pad[1] = c.pad[2] = 0.0;
-    out[i] = c;
+__global__ __launch_bounds__(256) void prep_frame_kernel(const PrepArgs a) {
+    const unsigned b = blockIdx.x;
+    if (b < a.nb_nodes) {
+        prep_node_quarter(a.nodes_in, a.nodes_out, a.n_nodes, (long long)b * 256 + threadIdx.x, a.ox, a.oy, a.oz);
+    } else if (b < a.nb_nodes + a.nb_tlas) {
+        prep_node_quarter(a.tlas_in, a.tlas_out, a.n_tlas, (long long)(b - a.nb_nodes) * 256 + threadIdx.x, a.ox, a.oy, a.oz);
+    } else if (a.tris_out) {
+        const long long i = (long long)(b - a.nb_nodes - a.nb_tlas) * 256 + threadIdx.x;
+        if (i >= a.n_tris) return;
+        const double* tp = a.tris + (size_t)i * 9;
+        const double v0x = tp[0], v0y = tp[1], v0z = tp[2];
+        CamTri c;
+        c.e0[0] = tp[3] - v0x;
+        c.e0[1] = tp[4] - v0y;
+        c.e0[2] = tp[5] - v0z;
+        c.e2[0] = tp[6] - v0x;
+        c.e2[1] = tp[7] - v0y;
+        c.e2[2] = tp[8] - v0z;
+        c.tv[0] = a.ox - v0x;
+        c.tv[1] = a.oy - v0y;
+        c.tv[2] = a.oz - v0z;
+        c.q[0] = c.tv[1] * c.e0[2] - c.tv[2] * c.e0[1];
+        c.q[1] = c.tv[2] * c.e0[0] - c.tv[0] * c.e0[2];
+        c.q[2] = c.tv[0] * c.e0[1] - c.tv[1] * c.e0[0];
+        c.tnum = (c.e2[0] * c.q[0] + c.e2[1] * c.q[1]) + c.e2[2] * c.q[2];
+        c.pad[0] = c.pad[1] = c.pad[2] = 0.0;
+        a.tris_out[i] = c;
+    }
 }
 
 struct PacketScene {
