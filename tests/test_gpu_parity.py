@@ -604,3 +604,58 @@ def test_pipelined_driver_equals_unpipelined_at_64_spp(tmp_path):
     r = subprocess.run([sys.executable, tool, "5", "512"], capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "all 10 files identical" in r.stdout
+
+
+def test_frame_groups_serve_consecutive_small_frames_and_the_state_catches_up(ctx, monkeypatch):
+    """Small frames: one jitter slot holds several consecutive frames (one set of jumps per group) and the device
+    generator state lags behind the position while a group is consumed.  Ten consecutive frames through rt_render
+    must equal the oracle's over one continuous stream (cpp/rtmathutils.h:15-16 is never reseeded); the state,
+    a seek and the jitter test seam in the middle of a group must see the true position; the same frames without
+    groups (RT_NO_FRAME_GROUPS) are identical."""
+    c, k = meshgen.plate(12)
+    host = ra.HostScene([c], [k], 0)
+    ctx.upload(host)
+    o = orc.Scene([c], [k], 0)
+    H, W, spp = 9, 14, 3
+    cam = meshgen.camera_arrays(W, H)
+    fw = H * W * spp * 4
+
+    def run(n_frames, check_state_at=()):
+        ctx.rng_seed(5489)
+        frames = []
+        for f in range(n_frames):
+            ctx.render(*cam, H, W, spp, hit_ids=True)
+            frames.append(ctx.download())
+            assert ctx.rng_tell() == (f + 1) * fw
+            if f in check_state_at:
+                # the window of raw words before the position (bits 0..30 of the oldest word are not state)
+                dev, want = ctx.rng_state(), ra.mt19937_state_at((f + 1) * fw)
+                assert np.array_equal(dev[1:], want[1:]) and (dev[0] >> 31) == (want[0] >> 31)
+        return frames
+
+    got = run(10, check_state_at=(0, 3, 4, 9))
+    rng = orc.Rng()
+    for f in range(10):
+        want = o.render(*cam, H, W, spp, rng=rng)
+        mesh, elem = host.map_prims(got[f]["hit_prim"])
+        assert np.array_equal(elem, want["hit_elem"]) and np.array_equal(bits(got[f]["intensity"]), bits(want["intensity"])), f
+    # in the middle of a group: the jitter seam continues the stream where the frames stopped, then frames go on
+    ctx.rng_seed(5489)
+    for f in range(3):
+        ctx.render(*cam, H, W, spp)
+    j = ctx.rng_jitter(10, 2)
+    rng = orc.Rng()
+    rng.discard(3 * fw)
+    assert np.array_equal(bits(j), bits(rng.doubles(10) - 0.5))
+    ctx.render(*cam, H, W, spp, hit_ids=True)
+    want = o.render(*cam, H, W, spp, rng=rng)
+    assert np.array_equal(bits(ctx.download()["intensity"]), bits(want["intensity"]))
+    # a seek back into the middle of what a group covered
+    ctx.rng_seek(2 * fw)
+    ctx.render(*cam, H, W, spp)
+    assert np.array_equal(bits(ctx.download()["intensity"]), bits(got[2]["intensity"]))
+    monkeypatch.setenv("RT_NO_FRAME_GROUPS", "1")
+    plain = run(10)
+    for f in range(10):
+        assert np.array_equal(bits(plain[f]["intensity"]), bits(got[f]["intensity"])), f
+    host.close()
