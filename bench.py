@@ -2,9 +2,13 @@
 """bench.py -- Mrays/s of the render hot path on MI355X (contract: see the round prompt / DESIGN.md).
 
 A "step" is one full frame of the workload: MT19937 jitter generation (GPU GF(2) jump-ahead kernels +
-jitter kernel, the host only supplies cached jump polynomials), ray generation, TLAS/BLAS traversal, Moller-Trumbore, shading, in-order sample accumulation,
-quantisation and per-sample hit-id output, with the flattened tree already resident in HBM (the host
-BVH build and the upload happen before the timed region and are reported separately).
+jitter kernel, the host only supplies cached jump polynomials), the per-frame camera-relative records (prep
+kernel) and cuts (cut kernels: the tree classified once per pixel block), ray generation,
+TLAS/BLAS traversal, Moller-Trumbore, shading, in-order sample accumulation, quantisation and per-sample
+hit-id output, with the flattened tree already resident in HBM (the host BVH build and the upload happen
+before the timed region and are reported separately).  Nothing is carried over from one step to the next but
+the sampler's look-ahead: records and cuts are made again for every frame, as a new camera or timestep would
+need them.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4|plate1m|sphere|block]
 
@@ -430,7 +434,9 @@ def main():
                     "node_records_per_ray": cs["wave_node_fetches"] / rays,
                     "tri_records_per_ray": cs["wave_tri_fetches"] / rays,
                     "note": "requested by the waves (scalar cache / L2 / MALL absorb most of it); an upper bound on "
-                            "what can reach HBM"}
+                            "what can reach HBM.  Counted, like nodes_per_ray / tris_per_ray, by the COUNT instantiation, "
+                            "which walks from the root under the reference's visit rule: the timed kernel starts at "
+                            "the blocks' cuts and fetches fewer node records than this"}
         # (3) what binds: fp64 VALU issue.  Instruction count from the committed PMC pass of THESE kernels
         #     (source hash must match), time from this run.
         traffic = None
@@ -597,11 +603,14 @@ def main():
                        "blas": int(host.info.n_meshes), "bvh_nodes": int(host.info.n_blas_nodes),
                        "sampler": "MT19937 reference stream (GPU GF(2) jump-ahead + jitter kernels, device-resident state)",
                        "hit_ids_written": want_ids, "frames_per_step_per_gpu": 1,
+                       "cuts": ("off (RT_NO_CUT)" if os.environ.get("RT_NO_CUT") else
+                                "made per frame for frames >= %g rays" % float(os.environ.get("RT_CUT_MIN_RAYS", 64e6))),
                        "host_threads_per_rank": int(ra.lib.rt_host_threads()),
                        "parallelism": f"frame-sharded x{world}, no collective"},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "aux": {"jitter_kernel_ms": jms, "host_jump_ms_per_frame": hjm, "host_bvh_build_s": build_s,
+                    "step_minus_traversal_kernel_ms": elapsed / args.steps * 1e3 - kms,
                     "upload_s": upload_s, "stack_need": int(host.info.stack_need),
                     "download_frame_ms": dl_frame_ms, "download_hit_ids_ms": dl_ids_ms,
                     "jitter_kernel_ms_timed_step": jitter_ms_last,

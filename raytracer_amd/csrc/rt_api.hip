@@ -1190,7 +1190,10 @@ int launch_packet(rt_ctx* c, const rt_render_params* p, int tile_log2, int tiles
     if (a.interleave && ((a.interleave & (a.interleave - 1)) || a.interleave > ((1 << (2 * tile_log2)) >> 2))) a.interleave = 0;
     a.fast_ok = (c->max_abs_coord + std::fabs(ox) + std::fabs(oy) + std::fabs(oz)) < 1e100 ? 2 : 0;
     CutTables ct;
-    int rc = make_cuts(c, p, tile_log2, a.fpv, pb.cam_nodes, pb.cam_tlas, pb.cuts, !count && a.fast_ok == 2, ct);
+    // (visit counters count the reference's visit rule, so a counting launch walks from the root; RT_COUNT_WITH_CUTS=1
+    // counts what the cut walk really fetches and tests instead -- profiling aid)
+    const bool count_cuts = std::getenv("RT_COUNT_WITH_CUTS") != nullptr;
+    int rc = make_cuts(c, p, tile_log2, a.fpv, pb.cam_nodes, pb.cam_tlas, pb.cuts, (!count || count_cuts) && a.fast_ok == 2, ct);
     if (rc) return rc;
     for (int l = 0; l < rtk::CUT_MAX_LEVELS; ++l) {
         a.cut_lvl[l] = ct.lvl[l];
