@@ -167,11 +167,21 @@ struct rt_ctx {
     };
     std::vector<std::unique_ptr<StagedSet>> staged;
     std::mutex staged_mu;
-    // camera-relative copies for the packet kernel (rebuilt per render by the prep kernels)
-    DevBuf<rt::DevNode> cam_nodes, cam_tlas;
-    DevBuf<rtk::CamTri> cam_tris;
-    DevBuf<uint32_t> cuts;  // per-tile entry lists of the last packet launch (tile_cut_kernel)
-    CutPlan cut_plan;             // levels of the last rt_render's cuts in `cuts`
+    // Camera-relative copies for the packet kernels and the cuts made from them, rebuilt per render by the prep and
+    // cut kernels.  Two sets used alternately: the prep + cut kernels of a launch run on prep_stream into the set
+    // the PREVIOUS launch is not reading, so they overlap that launch's traversal kernel (they are chains of short,
+    // latency-bound launches; the traversal is VALU-bound).  `ready`: the set's prep + cut kernels (prep_stream);
+    // `read_done`: the traversal kernel that last read it (c->stream).
+    struct CamSet {
+        DevBuf<rt::DevNode> nodes, tlas;
+        DevBuf<rtk::CamTri> tris;
+        DevBuf<uint32_t> cuts;  // per-block entry lists (cut_level_kernel)
+        hipEvent_t ready = nullptr, read_done = nullptr;
+        bool read_pending = false;
+    } cam[2];
+    int cam_idx = 0;                    // set of the last launch
+    hipStream_t prep_stream = nullptr;
+    CutPlan cut_plan;             // levels of the last rt_render's cuts in cam[cam_idx].cuts
     bool cut_plan_valid = false;  // false: the last render made none
     // fp32 fast path records (RT_FLAG_FP32), allocated on first use
     DevBuf<rtk32::Node32> nodes32;
@@ -797,6 +807,17 @@ rt_ctx* rt_create(int device) {
         g_err = "rt_create: hipStreamCreate failed";
         return nullptr;
     }
+    // the prep + cut kernels of the NEXT launch likewise go between the workgroups of the running traversal kernel
+    if (hipStreamCreateWithPriority(&c->prep_stream, hipStreamNonBlocking, prio_hi) != hipSuccess) {
+        g_err = "rt_create: hipStreamCreate failed";
+        return nullptr;
+    }
+    for (auto& cs : c->cam)
+        if (hipEventCreateWithFlags(&cs.ready, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&cs.read_done, hipEventDisableTiming) != hipSuccess) {
+            g_err = "rt_create: hipEventCreate failed";
+            return nullptr;
+        }
     for (auto& ev : c->ev)
         if (hipEventCreate(&ev) != hipSuccess) {
             g_err = "rt_create: hipEventCreate failed";
@@ -838,10 +859,15 @@ void rt_destroy(rt_ctx* c) {
     c->leaf_ext.release();
     c->tris.release();
     c->colors.release();
-    c->cam_nodes.release();
-    c->cam_tlas.release();
-    c->cam_tris.release();
-    c->cuts.release();
+    if (c->prep_stream) (void)hipStreamSynchronize(c->prep_stream);
+    for (auto& cs : c->cam) {
+        cs.nodes.release();
+        cs.tlas.release();
+        cs.tris.release();
+        cs.cuts.release();
+        if (cs.ready) (void)hipEventDestroy(cs.ready);
+        if (cs.read_done) (void)hipEventDestroy(cs.read_done);
+    }
     c->nodes32.release();
     c->tlas32.release();
     c->tris32.release();
@@ -902,6 +928,7 @@ void rt_destroy(rt_ctx* c) {
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->rng_stream) (void)hipStreamDestroy(c->rng_stream);
+    if (c->prep_stream) (void)hipStreamDestroy(c->prep_stream);
     delete c;
 }
 
@@ -909,6 +936,7 @@ int rt_sync(rt_ctx* c) {
     if (!c) return fail(RT_E_INVALID, "rt_sync: null context");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->rng_stream));
+    HIP_TRY(hipStreamSynchronize(c->prep_stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return RT_OK;
 }
@@ -1059,8 +1087,8 @@ struct PacketBuffers {
 };
 
 // Camera-relative node / TLAS / triangle records of a frame in one launch (tris_out = null: boxes only).
-void launch_prep(rt_ctx* c, rt::DevNode* cam_nodes, rt::DevNode* cam_tlas, rtk::CamTri* cam_tris, double ox, double oy,
-                 double oz) {
+void launch_prep(rt_ctx* c, hipStream_t st, rt::DevNode* cam_nodes, rt::DevNode* cam_tlas, rtk::CamTri* cam_tris, double ox,
+                 double oy, double oz) {
     rtk::PrepArgs pa;
     pa.nodes_in = c->nodes.p;
     pa.nodes_out = cam_nodes;
@@ -1077,7 +1105,7 @@ void launch_prep(rt_ctx* c, rt::DevNode* cam_nodes, rt::DevNode* cam_tlas, rtk::
     pa.nb_nodes = (unsigned)((4 * c->n_nodes + 255) / 256);
     pa.nb_tlas = (unsigned)((4 * c->n_tlas + 255) / 256);
     const unsigned nb_tris = (unsigned)((pa.n_tris + 255) / 256);
-    hipLaunchKernelGGL(rtk::prep_frame_kernel, dim3(pa.nb_nodes + pa.nb_tlas + nb_tris), dim3(256), 0, c->stream, pa);
+    hipLaunchKernelGGL(rtk::prep_frame_kernel, dim3(pa.nb_nodes + pa.nb_tlas + nb_tris), dim3(256), 0, st, pa);
 }
 
 // What a render kernel is told about the cuts of its launch (rtk::PacketArgs / rtk32::Packet32Args).
@@ -1088,12 +1116,13 @@ struct CutTables {
     int32_t lo = -1;  // < 0: no cuts, every batch walks from the root
 };
 
-// The cut kernels of one launch (cut_level_kernel, level after level) on c->stream, from the camera-relative boxes
+// The cut kernels of one launch (cut_level_kernel, level after level) on stream `st`, from the camera-relative boxes
 // the prep kernels have written.  `allowed`: not with visit counters (they count the reference's visit rule), not
 // without min <= max boxes and tame coordinates (the cut's argument rests on the NaN-free slab test).  Allocates
 // nothing; `cuts` = plan_cuts(...).total_words words, or null.
-int make_cuts(rt_ctx* c, const rt_render_params* p, int tile_log2, const rtk::FrameParams& fp, const rt::DevNode* cam_nodes,
-              const rt::DevNode* cam_tlas, uint32_t* cuts, bool allowed, CutTables& out) {
+int make_cuts(rt_ctx* c, hipStream_t st, const rt_render_params* p, int tile_log2, const rtk::FrameParams& fp,
+              const rt::DevNode* cam_nodes, const rt::DevNode* cam_tlas, const rtk::CamTri* cam_tris, uint32_t* cuts,
+              bool allowed, CutTables& out) {
     out = CutTables{};
     const int W = p->image_width, spp = p->samples, rows = p->row_end - p->row_begin;
     const bool no_cut = std::getenv("RT_NO_CUT") != nullptr;  // (comparison / test knob, read per launch)
@@ -1124,10 +1153,12 @@ int make_cuts(rt_ctx* c, const rt_render_params* p, int tile_log2, const rtk::Fr
         ca.tiles_x = cp.tiles_x[l];
         ca.n_tiles = (int32_t)cp.tiles[l];
         ca.cuts = cuts + cp.offset_words[l];
+        // the finest level's leaves lose the triangles no ray of the block can hit (cut_trim); RT_NO_TRIM: comparison knob
+        ca.tris = (l == cp.lo && !std::getenv("RT_NO_TRIM")) ? cam_tris : nullptr;
         const int64_t patches = int64_t((cp.tiles_x[l] + 7) / 8) * ((cp.tiles[l] / cp.tiles_x[l] + 7) / 8);
         const int per_wg = rtk::CUT_THREADS / 64;  // one 8 x 8 patch of blocks per wave
         hipLaunchKernelGGL(rtk::cut_level_kernel, dim3((unsigned)((patches + per_wg - 1) / per_wg)), dim3(rtk::CUT_THREADS),
-                           0, c->stream, ca);
+                           0, st, ca);
         ca.parent = ca.cuts;
         ca.parent_tiles_x = ca.tiles_x;
     }
@@ -1144,14 +1175,41 @@ int make_cuts(rt_ctx* c, const rt_render_params* p, int tile_log2, const rtk::Fr
     return RT_OK;
 }
 
-// prep kernels + render_packet_kernel on c->stream, bracketed by the context's timing events.  Allocates nothing.
-int launch_packet(rt_ctx* c, const rt_render_params* p, int tile_log2, int tiles_x, int64_t n_tiles, const PacketBuffers& pb,
-                  bool* cuts_made = nullptr) {
-    const int W = p->image_width, spp = p->samples, rows = p->row_end - p->row_begin;
+// What the prep + cut kernels of a packet launch leave for its traversal kernel.
+struct PacketPrep {
+    rtk::FrameParams fpv;
+    CutTables ct;
+    int fast_ok = 0;
+};
+
+// Prep kernel + cut kernels of one packet launch on stream `st` (c->stream, or prep_stream with the caller's
+// events around it).  Allocates nothing.
+int launch_packet_prep(rt_ctx* c, hipStream_t st, const rt_render_params* p, int tile_log2, const PacketBuffers& pb,
+                       PacketPrep& pp) {
     const bool count = pb.counters != nullptr;
     const double ox = p->camera_center[0], oy = p->camera_center[1], oz = p->camera_center[2];
-    launch_prep(c, pb.cam_nodes, pb.cam_tlas, pb.cam_tris, ox, oy, oz);
+    launch_prep(c, st, pb.cam_nodes, pb.cam_tlas, pb.cam_tris, ox, oy, oz);
     HIP_TRY(hipGetLastError());
+    for (int i = 0; i < 3; ++i) {
+        pp.fpv.cam[i] = p->camera_center[i];
+        pp.fpv.p00[i] = p->pixel_00_center[i];
+    }
+    for (int i = 0; i < 6; ++i) pp.fpv.sp[i] = p->pixel_spacing[i];
+    // finite coordinates => every node box (>= 1 triangle, rt_scene_build rejects empty meshes) has
+    // min <= max, and so has its camera-relative copy (subtraction rounds monotonically): level 2
+    pp.fast_ok = (c->max_abs_coord + std::fabs(ox) + std::fabs(oy) + std::fabs(oz)) < 1e100 ? 2 : 0;
+    // (visit counters count the reference's visit rule, so a counting launch walks from the root; RT_COUNT_WITH_CUTS=1
+    // counts what the cut walk really fetches and tests instead -- profiling aid)
+    const bool count_cuts = std::getenv("RT_COUNT_WITH_CUTS") != nullptr;
+    return make_cuts(c, st, p, tile_log2, pp.fpv, pb.cam_nodes, pb.cam_tlas, pb.cam_tris, pb.cuts,
+                     (!count || count_cuts) && pp.fast_ok == 2, pp.ct);
+}
+
+// render_packet_kernel on c->stream, bracketed by the context's timing events.  Allocates nothing.
+int launch_packet_kernel(rt_ctx* c, const rt_render_params* p, int tile_log2, int tiles_x, int64_t n_tiles,
+                         const PacketBuffers& pb, const PacketPrep& pp, bool* cuts_made = nullptr) {
+    const int W = p->image_width, spp = p->samples, rows = p->row_end - p->row_begin;
+    const bool count = pb.counters != nullptr;
     rtk::PacketArgs a;
     a.sc.nodes = pb.cam_nodes;
     a.sc.tlas = pb.cam_tlas;
@@ -1159,11 +1217,7 @@ int launch_packet(rt_ctx* c, const rt_render_params* p, int tile_log2, int tiles
     a.sc.leaf_ext = c->leaf_ext.p;
     a.sc.tris = pb.cam_tris;
     a.sc.colors = c->colors.p;
-    for (int i = 0; i < 3; ++i) {
-        a.fpv.cam[i] = p->camera_center[i];
-        a.fpv.p00[i] = p->pixel_00_center[i];
-    }
-    for (int i = 0; i < 6; ++i) a.fpv.sp[i] = p->pixel_spacing[i];
+    a.fpv = pp.fpv;
     a.W = W;
     a.spp = spp;
     a.row0 = p->row_begin;
@@ -1177,8 +1231,6 @@ int launch_packet(rt_ctx* c, const rt_render_params* p, int tile_log2, int tiles
     a.hit_prim = pb.hit_prim;
     a.hit_t = pb.hit_t;
     a.counters = pb.counters;
-    // finite coordinates => every node box (>= 1 triangle, rt_scene_build rejects empty meshes) has
-    // min <= max, and so has its camera-relative copy (subtraction rounds monotonically): level 2
     a.pair64 = 0;  // 1 + log2(spp / 64) for spp = 64, 128, 256, ...: the one-pixel-per-batch instantiation
     // (an even number of batches per wave: 16 or 4 pixels per wave, or one pixel of >= 128 samples)
     if (spp >= 64 && (spp & (spp - 1)) == 0 && (tile_log2 == 3 || tile_log2 == 2 || (tile_log2 == 1 && spp >= 128)) &&
@@ -1188,19 +1240,13 @@ int launch_packet(rt_ctx* c, const rt_render_params* p, int tile_log2, int tiles
     a.interleave = std::getenv("RT_NO_INTERLEAVE") ? 0 : (a.pair64 ? 1 : 0);
     if (const char* e = std::getenv("RT_INTERLEAVE")) a.interleave = std::atoi(e);  // experiment: 0, 1, 2, 4, ...
     if (a.interleave && ((a.interleave & (a.interleave - 1)) || a.interleave > ((1 << (2 * tile_log2)) >> 2))) a.interleave = 0;
-    a.fast_ok = (c->max_abs_coord + std::fabs(ox) + std::fabs(oy) + std::fabs(oz)) < 1e100 ? 2 : 0;
-    CutTables ct;
-    // (visit counters count the reference's visit rule, so a counting launch walks from the root; RT_COUNT_WITH_CUTS=1
-    // counts what the cut walk really fetches and tests instead -- profiling aid)
-    const bool count_cuts = std::getenv("RT_COUNT_WITH_CUTS") != nullptr;
-    int rc = make_cuts(c, p, tile_log2, a.fpv, pb.cam_nodes, pb.cam_tlas, pb.cuts, (!count || count_cuts) && a.fast_ok == 2, ct);
-    if (rc) return rc;
+    a.fast_ok = pp.fast_ok;
     for (int l = 0; l < rtk::CUT_MAX_LEVELS; ++l) {
-        a.cut_lvl[l] = ct.lvl[l];
-        a.cut_tx[l] = ct.tx[l];
-        a.cut_eff[l] = ct.eff[l];
+        a.cut_lvl[l] = pp.ct.lvl[l];
+        a.cut_tx[l] = pp.ct.tx[l];
+        a.cut_eff[l] = pp.ct.eff[l];
     }
-    a.cut_lo = ct.lo;
+    a.cut_lo = pp.ct.lo;
     if (cuts_made) *cuts_made = a.cut_lo >= 0;
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     if (count && a.pair64)
@@ -1214,6 +1260,15 @@ int launch_packet(rt_ctx* c, const rt_render_params* p, int tile_log2, int tiles
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev[1], c->stream));
     return RT_OK;
+}
+
+// Both on c->stream (rt_render_static).
+int launch_packet(rt_ctx* c, const rt_render_params* p, int tile_log2, int tiles_x, int64_t n_tiles, const PacketBuffers& pb,
+                  bool* cuts_made = nullptr) {
+    PacketPrep pp;
+    int rc = launch_packet_prep(c, c->stream, p, tile_log2, pb, pp);
+    if (rc) return rc;
+    return launch_packet_kernel(c, p, tile_log2, tiles_x, n_tiles, pb, pp, cuts_made);
 }
 
 // rt_render.  `pipelined` (rt_render_scene only, plain MT19937 frames without per-sample outputs): the
@@ -1238,6 +1293,46 @@ int render_impl(rt_ctx* c, const rt_render_params* p, bool pipelined) {
     const size_t n_smp = n_pix * size_t(spp);
     HIP_TRY(hipSetDevice(c->device));
     pipelined = pipelined && p->sampler == RT_SAMPLER_MT19937 && p->flags == 0;
+    int rc;
+    // ---- traversal launch shape ----
+    // the packet kernels address nodes with a 32-bit scalar byte offset: node array < 4 GB (6.7e7 nodes)
+    const bool packet = c->stack_need <= rtk::PACKET_STACK && !force_per_lane() && c->n_nodes < (size_t(1) << 26);
+    const int tile_log2 = pick_tile_log2(packet || (p->flags & RT_FLAG_FP32), spp, W, rows);
+    const int ts = 1 << tile_log2;
+    const int tiles_x = (W + ts - 1) / ts;
+    const int tiles_y = (rows + ts - 1) / ts;
+    const int64_t n_tiles = int64_t(tiles_x) * tiles_y;
+    if (n_tiles > 0x7fffffff) return fail(RT_E_LIMIT, "rt_render: too many tiles");
+    const bool count = (p->flags & RT_FLAG_COUNTERS) != 0;
+    if ((rc = c->counters.ensure(8))) return rc;
+    // ---- prep + cut kernels of a packet launch: before anything waits for the previous launch, on prep_stream,
+    // into the camera set that launch is not reading -- they run while its traversal kernel still does
+    const bool packet_launch = packet && !(p->flags & RT_FLAG_FP32);
+    PacketBuffers pb{};
+    PacketPrep pp;
+    rt_ctx::CamSet* cs = nullptr;
+    CutPlan cp;
+    const bool overlap = std::getenv("RT_NO_PREP_OVERLAP") == nullptr;  // (comparison knob, read per launch)
+    if (packet_launch) {
+        c->cam_idx ^= 1;
+        cs = &c->cam[c->cam_idx];
+        if ((rc = cs->nodes.ensure(c->n_nodes))) return rc;
+        if ((rc = cs->tlas.ensure(c->n_tlas))) return rc;
+        if ((rc = cs->tris.ensure((size_t)c->n_tris))) return rc;
+        cp = plan_cuts(W, rows, spp, tile_log2);
+        if (cp.tiles[cp.lo] > 0x7fffffff) return fail(RT_E_LIMIT, "rt_render: too many pixel blocks");
+        if ((rc = cs->cuts.ensure(size_t(cp.total_words)))) return rc;
+        pb.cam_nodes = cs->nodes.p;
+        pb.cam_tlas = cs->tlas.p;
+        pb.cam_tris = cs->tris.p;
+        pb.cuts = cs->cuts.p;
+        pb.counters = count ? c->counters.p : nullptr;
+        const hipStream_t st = overlap ? c->prep_stream : c->stream;
+        // the set was last read by the launch before the previous one (or by an fp32 launch)
+        if (overlap && cs->read_pending) HIP_TRY(hipStreamWaitEvent(st, cs->read_done, 0));
+        if ((rc = launch_packet_prep(c, st, p, tile_log2, pb, pp))) return rc;
+        if (overlap) HIP_TRY(hipEventRecord(cs->ready, st));
+    }
     // outputs / jitter of the previous call may still be in flight
     if (!pipelined) {
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1251,7 +1346,6 @@ int render_impl(rt_ctx* c, const rt_render_params* p, bool pipelined) {
     // slots' events, and a fill of several frames must not hold up the frames the slot in use still serves.)
     if (p->sampler != RT_SAMPLER_MT19937) HIP_TRY(hipStreamSynchronize(c->rng_stream));
 
-    int rc;
     // the previous launch's frame moves to prev_* (its kernel may still be writing it: only the
     // pointers move); this launch writes the other pair
     std::swap(c->intensity, c->prev_intensity);
@@ -1337,15 +1431,6 @@ int render_impl(rt_ctx* c, const rt_render_params* p, bool pipelined) {
     const double* d_jitter = c->slot[use].buf.p + size_t(slot_frame) * n_smp * 2;
 
     // ---- traversal ----
-    // the packet kernels address nodes with a 32-bit scalar byte offset: node array < 4 GB (6.7e7 nodes)
-    const bool packet = c->stack_need <= rtk::PACKET_STACK && !force_per_lane() && c->n_nodes < (size_t(1) << 26);
-    const int tile_log2 = pick_tile_log2(packet || (p->flags & RT_FLAG_FP32), spp, W, rows);
-    const int ts = 1 << tile_log2;
-    const int tiles_x = (W + ts - 1) / ts;
-    const int tiles_y = (rows + ts - 1) / ts;
-    const int64_t n_tiles = int64_t(tiles_x) * tiles_y;
-    if (n_tiles > 0x7fffffff) return fail(RT_E_LIMIT, "rt_render: too many tiles");
-    const bool count = (p->flags & RT_FLAG_COUNTERS) != 0;
     if (count) HIP_TRY(hipMemsetAsync(c->counters.p, 0, 8 * sizeof(unsigned long long), c->stream));
     c->stats_counters = count ? c->counters.p : nullptr;
     if (p->flags & RT_FLAG_FP32) {
@@ -1374,13 +1459,16 @@ int render_impl(rt_ctx* c, const rt_render_params* p, bool pipelined) {
         // cuts: made from the exact camera-relative boxes (the fp32 records share the node numbering)
         CutTables ct;
         {
-            const CutPlan cp = plan_cuts(W, rows, spp, tile_log2);
-            if ((rc = c->cam_nodes.ensure(c->n_nodes))) return rc;
-            if ((rc = c->cam_tlas.ensure(c->n_tlas))) return rc;
-            if ((rc = c->cuts.ensure(size_t(cp.total_words)))) return rc;
-            launch_prep(c, c->cam_nodes.p, c->cam_tlas.p, nullptr, ox, oy, oz);
+            // (all on c->stream, in the set of the last launch: ordered behind that launch's kernel)
+            cp = plan_cuts(W, rows, spp, tile_log2);
+            cs = &c->cam[c->cam_idx];
+            if ((rc = cs->nodes.ensure(c->n_nodes))) return rc;
+            if ((rc = cs->tlas.ensure(c->n_tlas))) return rc;
+            if ((rc = cs->cuts.ensure(size_t(cp.total_words)))) return rc;
+            launch_prep(c, c->stream, cs->nodes.p, cs->tlas.p, nullptr, ox, oy, oz);
             const bool tame = (c->max_abs_coord + std::fabs(ox) + std::fabs(oy) + std::fabs(oz)) < 1e30;
-            if ((rc = make_cuts(c, p, tile_log2, h_frame_params, c->cam_nodes.p, c->cam_tlas.p, c->cuts.p, !count && tame, ct)))
+            if ((rc = make_cuts(c, c->stream, p, tile_log2, h_frame_params, cs->nodes.p, cs->tlas.p, nullptr, cs->cuts.p,
+                                !count && tame, ct)))
                 return rc;
             c->cut_plan = cp;
             c->cut_plan_valid = ct.lo >= 0;
@@ -1422,26 +1510,16 @@ int render_impl(rt_ctx* c, const rt_render_params* p, bool pipelined) {
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->ev[1], c->stream));
     } else if (packet) {
-        // Wave-packet traversal on camera-relative records (see rt_kernels.hip.hpp).
-        if ((rc = c->cam_nodes.ensure(c->n_nodes))) return rc;
-        if ((rc = c->cam_tlas.ensure(c->n_tlas))) return rc;
-        if ((rc = c->cam_tris.ensure((size_t)c->n_tris))) return rc;
-        PacketBuffers pb;
-        pb.cam_nodes = c->cam_nodes.p;
-        pb.cam_tlas = c->cam_tlas.p;
-        pb.cam_tris = c->cam_tris.p;
+        // Wave-packet traversal on camera-relative records (see rt_kernels.hip.hpp); they and the cuts are on their
+        // way or done (above)
         pb.jitter = d_jitter;
         pb.intensity = c->intensity.p;
         pb.rgb = c->rgb.p;
         pb.hit_prim = (p->flags & RT_FLAG_HIT_IDS) ? c->hit_prim.p : nullptr;
         pb.hit_t = (p->flags & RT_FLAG_HIT_T) ? c->hit_t.p : nullptr;
-        pb.counters = count ? c->counters.p : nullptr;
-        const CutPlan cp = plan_cuts(W, rows, spp, tile_log2);
-        if (cp.tiles[cp.lo] > 0x7fffffff) return fail(RT_E_LIMIT, "rt_render: too many pixel blocks");
-        if ((rc = c->cuts.ensure(size_t(cp.total_words)))) return rc;
-        pb.cuts = c->cuts.p;
+        if (overlap) HIP_TRY(hipStreamWaitEvent(c->stream, cs->ready, 0));
         bool cuts_made = false;
-        if ((rc = launch_packet(c, p, tile_log2, tiles_x, n_tiles, pb, &cuts_made))) return rc;
+        if ((rc = launch_packet_kernel(c, p, tile_log2, tiles_x, n_tiles, pb, pp, &cuts_made))) return rc;
         c->cut_plan = cp;
         c->cut_plan_valid = cuts_made;
     } else {
@@ -1481,6 +1559,10 @@ int render_impl(rt_ctx* c, const rt_render_params* p, bool pipelined) {
             launch_render<false>(stack, dim3((unsigned)n_tiles), c->stream, a);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    }
+    if (cs) {  // the camera set's next prep (two launches on, on prep_stream) waits for this kernel
+        HIP_TRY(hipEventRecord(cs->read_done, c->stream));
+        cs->read_pending = true;
     }
     HIP_TRY(hipEventRecord(c->front_last_use, c->stream));  // rt_upload_scene waits for it before reusing the set
     c->front_used = true;
@@ -1706,6 +1788,22 @@ int rt_tile_cuts_host(const rt_scene* scene, const rt_render_params* p, int leve
     };
     const std::vector<rt::DevNode> nodes = relative(s.dev_nodes.data(), s.dev_nodes.size());
     const std::vector<rt::DevNode> tlas = relative(s.dev_tlas.data(), s.dev_tlas.size());
+    // camera-relative triangle records, likewise
+    std::vector<rtk::CamTri> tris(s.prim_mesh.size());
+    for (size_t i = 0; i < tris.size(); ++i) {
+        const double* tp = s.tris.data() + i * 9;
+        rtk::CamTri& t = tris[i];
+        for (int k = 0; k < 3; ++k) {
+            t.e0[k] = tp[3 + k] - tp[k];
+            t.e2[k] = tp[6 + k] - tp[k];
+            t.tv[k] = p->camera_center[k] - tp[k];
+        }
+        t.q[0] = t.tv[1] * t.e0[2] - t.tv[2] * t.e0[1];
+        t.q[1] = t.tv[2] * t.e0[0] - t.tv[0] * t.e0[2];
+        t.q[2] = t.tv[0] * t.e0[1] - t.tv[1] * t.e0[0];
+        t.tnum = (t.e2[0] * t.q[0] + t.e2[1] * t.q[1]) + t.e2[2] * t.q[2];
+        t.pad[0] = t.pad[1] = t.pad[2] = 0.0;
+    }
     rtk::CutArgs ca;
     ca.nodes = nodes.data();
     ca.tlas = tlas.data();
@@ -1734,7 +1832,11 @@ int rt_tile_cuts_host(const rt_scene* scene, const rt_render_params* p, int leve
         ca.tiles_x = cp.tiles_x[l];
         ca.n_tiles = (int32_t)cp.tiles[l];
         ca.cuts = cur.data();
-        for (int64_t t = 0; t < cp.tiles[l]; ++t) rtk::cut_refine(ca, (int)t, lists, 1);
+        ca.tris = (l == cp.lo && !std::getenv("RT_NO_TRIM")) ? tris.data() : nullptr;
+        for (int64_t t = 0; t < cp.tiles[l]; ++t) {
+            rtk::cut_refine(ca, (int)t, lists, 1);
+            if (ca.tris) rtk::cut_trim(ca, (int)t, lists, 1);
+        }
         prev.swap(cur);
         ca.parent = prev.data();
         ca.parent_tiles_x = ca.tiles_x;
@@ -1757,7 +1859,7 @@ int rt_last_cuts(rt_ctx* c, int level, uint32_t* words, int64_t capacity_words, 
     const int64_t n = cp.tiles[level] * rtk::CUT_WORDS;
     if (words) {
         if (capacity_words < n) return fail(RT_E_INVALID, "rt_last_cuts: buffer too small");
-        HIP_TRY(hipMemcpy(words, c->cuts.p + cp.offset_words[level], size_t(n) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(words, c->cam[c->cam_idx].cuts.p + cp.offset_words[level], size_t(n) * sizeof(uint32_t), hipMemcpyDeviceToHost));
     }
     return (int)std::min<int64_t>(cp.tiles[level], 0x7fffffff);
 }

@@ -591,6 +591,10 @@ struct WaveCounters {
 };
 
 constexpr uint32_t CUT_NODE_ENTRY = rt::DESC_TLAS | rt::DESC_ROOT;  // cut entry: BLAS node tested per ray (see "Tile cuts")
+// A CUT_NODE_ENTRY with this bit names a LEAF whose triangle range is overridden by the NEXT word of the list (a leaf
+// descriptor of a sub-range: cut_trim).  Cuts are only made for the packet kernels, whose node indices are < 2^26.
+constexpr uint32_t CUT_TRIM = 0x10000000u;
+constexpr uint32_t CUT_NODE_IDX = 0x03FFFFFFu;
 
 // Entry list (tile cut, see cut_level_kernel): n_entries < 0 -- walk from the TLAS root (the reference's own walk);
 // otherwise lane 1 + i of `vlist` holds entry i, a descriptor at which the walk (re)starts with every valid lane
@@ -741,9 +745,14 @@ __device__ __forceinline__ void trace_packet(const PacketScene& sc, const unsign
                 if ((cur & CUT_NODE_ENTRY) == CUT_NODE_ENTRY) {
                     // entry of a cut: a BLAS node whose own box is tested per ray (the reference tests it when it
                     // pops the node); lanes that pass walk on from it
-                    sload_node(sc.nodes + (cur & 0x1FFFFFFFu), b, left, count, first, desc);
+                    sload_node(sc.nodes + (cur & CUT_NODE_IDX), b, left, count, first, desc);
                     if (COUNT) wc.nodes += (unsigned)__builtin_popcountll(inm);
                     const unsigned long long hm = slab_rel<FAST, OCT>(b, ix, iy, iz) & inm;
+                    if (cur & CUT_TRIM) {
+                        // a leaf whose live triangles are named by the next word of the list (cut_trim)
+                        ++ei;
+                        desc = (uint32_t)__builtin_amdgcn_readlane((int)vlist, ei);
+                    }
                     if (hm != 0ull) {
                         cur = desc;
                         inm = hm;
@@ -886,8 +895,8 @@ __device__ __forceinline__ void tile_coords(const int tile, const int n_tiles, c
 constexpr int CUT_WORDS = 32;                // header + entries per block (128 bytes)
 constexpr int CUT_CAP = CUT_WORDS - 1;       // entries
 constexpr uint32_t CUT_VALID = 0x80000000u;  // header: bit31 valid, bits 13..8 axis kinds (2 bits each), bits 7..0 entries
-constexpr uint32_t CUT_NODE = rt::DESC_TLAS | rt::DESC_ROOT;  // entry: BLAS node (bits 28..0) tested per ray
-constexpr int CUT_THREADS = 256;
+constexpr uint32_t CUT_NODE = rt::DESC_TLAS | rt::DESC_ROOT;  // entry: BLAS node (bits 25..0) tested per ray
+constexpr int CUT_THREADS = 64;  // one wave, 8 KB of LDS: fits the hole a retiring render workgroup (4 waves, 20 KB) leaves
 constexpr int CUT_MAX_LEVELS = 5;  // levels the render kernel reads: blocks of 1, 2, 4, 8, 16 pixels
 
 struct TileRays {
@@ -950,6 +959,8 @@ struct CutArgs {
     double mag;                // bound of the magnitudes any sample position of the image is computed from
     int32_t cap;               // entries a list of this level may hold (<= CUT_CAP)
     uint32_t* cuts;            // n_tiles * CUT_WORDS
+    const CamTri* tris;        // camera-relative triangle records: the lists' leaves are trimmed (cut_trim; the finest
+                               // level only -- no level may inherit from a trimmed one), or null
 };
 
 // max over the image's sample positions and components of |p00| + |s0 row0| + |s1 row1| + |cam|
@@ -965,8 +976,8 @@ __host__ __device__ inline double cut_magnitude(const FrameParams& fp, const int
     return mag;
 }
 
-// The sample rectangle of a block and its corner rays.  false: no cut for this block (degenerate camera).
-__host__ __device__ inline bool cut_tile_rays(const CutArgs& a, const int tix, const int tiy, TileRays& tr) {
+// The un-normalised rays through the corners of a block's sample rectangle.
+__host__ __device__ inline void cut_corner_rays(const CutArgs& a, const int tix, const int tiy, double (&dd)[4][3]) {
     const int ts = 1 << a.lvl;
     // sample positions px + [-0.5, 0.5] (cpp/rtrender.cpp:53-56), a little padded; blocks of the image's last
     // column / row are cut to the image
@@ -975,14 +986,19 @@ __host__ __device__ inline bool cut_tile_rays(const CutArgs& a, const int tix, c
     const double pad = 0.5 + 0x1p-20;
     const double s0v[2] = {(double)(tix * ts) - pad, (double)x1 + pad};
     const double s1v[2] = {(double)(tiy * ts + a.row0) - pad, (double)(y1 + a.row0) + pad};
-    double dd[4][3];
-    const double mag = a.mag;  // (host: cut_magnitude) bounds what the per-ray sample position is computed from
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const double s0 = s0v[c & 1], s1 = s1v[c >> 1];
 #pragma unroll
         for (int k = 0; k < 3; ++k) dd[c][k] = ((a.fp.p00[k] + s0 * a.fp.sp[k]) + s1 * a.fp.sp[3 + k]) - a.fp.cam[k];
     }
+}
+
+// The sample rectangle of a block and its corner rays.  false: no cut for this block (degenerate camera).
+__host__ __device__ inline bool cut_tile_rays(const CutArgs& a, const int tix, const int tiy, TileRays& tr) {
+    double dd[4][3];
+    const double mag = a.mag;  // (host: cut_magnitude) bounds what the per-ray sample position is computed from
+    cut_corner_rays(a, tix, tiy, dd);
     double big = 0.0;
     bool finite = true;
 #pragma unroll
@@ -1105,6 +1121,139 @@ __host__ __device__ inline void cut_refine(const CutArgs& a, const int tile, uin
              (uint32_t)n;
 }
 
+// ---- triangles of a block's leaves that no ray of the block can hit ----
+// A leaf's triangles are tested one after the other with a strict `<` on t (tri_test above): a triangle that every
+// ray of the block misses changes nothing, so the list may name the leaf's remaining triangles instead of the leaf.
+// With the record's values (e0, e2, tv, q: the per-ray test reads exactly these) and the true ray d = dd / |dd|,
+//     det = d . (e2 x e0),   unum = d . (e2 x tv),   vnum = d . q
+// in exact arithmetic, and the test fails when det <= 1e-6, unum / det < 0, vnum / det < 0 or (unum + vnum) / det > 1.
+// Each numerator times |dd| is AFFINE in the sample position, so over the block's sample rectangle it takes its
+// extremes at the corners; the triangle is dropped when at all four corners, by a margin,
+//     L_d < 0,  or  L_u < 0,  or  L_v < 0,  or  L_u + L_v - L_d > 0          (L_x = dd . N_x).
+// Margin: the per-ray values differ from the exact ones by the rounding of the sample position (|dd_fl - dd| <= eta
+// = 2^-50 mag per component), of the normalisation (3 ulp) and of the products and sums (< 16 ulp of the product of
+// the norms M_x); the margin taken is M_x (1e-9 max|dd| + 4 eta), five orders of magnitude more, so that the rounded
+// numerator keeps its sign with |value| > 0.9e-9 M_x -- a normal number, and so is its product with 1 / det
+// (1e-6 < det < 2.4e201) as long as M_x > 1e-60, which is asked for; for u + v > 1 the rounded numerators exceed
+// det by 0.9e-9 S, S = M_u + M_v + M_d >= det, against < 1e-14 S of rounding in the two quotients and their sum.
+// Blocks without a sign-keeping axis (|dd| may get close to zero) are left alone.  NaN / inf compare false: kept.
+// Bit m of the result: triangle m of the range is kept.
+__host__ __device__ inline uint32_t cut_live_triangles(const CamTri* tris, const uint32_t first, const uint32_t cnt,
+                                                      const double (&dd)[4][3], const double slack) {
+    uint32_t live = 0u;
+    for (uint32_t m = 0; m < cnt; ++m) {
+        const CamTri& t = tris[first + m];
+        const double e0x = t.e0[0], e0y = t.e0[1], e0z = t.e0[2];
+        const double e2x = t.e2[0], e2y = t.e2[1], e2z = t.e2[2];
+        const double tvx = t.tv[0], tvy = t.tv[1], tvz = t.tv[2];
+        const double qx = t.q[0], qy = t.q[1], qz = t.q[2];
+        // N_d = e2 x e0, N_u = e2 x tv
+        const double ndx = e2y * e0z - e2z * e0y, ndy = e2z * e0x - e2x * e0z, ndz = e2x * e0y - e2y * e0x;
+        const double nux = e2y * tvz - e2z * tvy, nuy = e2z * tvx - e2x * tvz, nuz = e2x * tvy - e2y * tvx;
+        const double a0 = __builtin_fabs(e0x) + __builtin_fabs(e0y) + __builtin_fabs(e0z);
+        const double a2 = __builtin_fabs(e2x) + __builtin_fabs(e2y) + __builtin_fabs(e2z);
+        const double at = __builtin_fabs(tvx) + __builtin_fabs(tvy) + __builtin_fabs(tvz);
+        const double m_d = a0 * a2, m_u = at * a2, m_v = __builtin_fabs(qx) + __builtin_fabs(qy) + __builtin_fabs(qz);
+        const double m_s = (m_d + m_u) + m_v;
+        bool d_neg = true, u_neg = m_u > 1e-60, v_neg = m_v > 1e-60, w_pos = m_s > 1e-60;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const double ld = (dd[c][0] * ndx + dd[c][1] * ndy) + dd[c][2] * ndz;
+            const double lu = (dd[c][0] * nux + dd[c][1] * nuy) + dd[c][2] * nuz;
+            const double lv = (dd[c][0] * qx + dd[c][1] * qy) + dd[c][2] * qz;
+            d_neg = d_neg && (ld < -(m_d * slack));
+            u_neg = u_neg && (lu < -(m_u * slack));
+            v_neg = v_neg && (lv < -(m_v * slack));
+            w_pos = w_pos && (((lu + lv) - ld) > m_s * slack);
+        }
+        if (!(d_neg || u_neg || v_neg || w_pos)) live |= 1u << m;
+    }
+    return live;
+}
+
+// Rewrites a finished list (cut_refine) with its leaves trimmed.  Leaves of <= 7 triangles only (others stay):
+//   sure leaf (descriptor)     -> the runs of its live triangles as leaf descriptors of their own, in order, while
+//                                 the list has room, else the one range from the first to the last live triangle;
+//   leaf tested per ray        -> CUT_NODE | CUT_TRIM | index, then the descriptor of that one range;
+//   no live triangle           -> the entry goes (with its box test).
+// Never longer than CUT_CAP: an entry takes more than one word only while every entry after it still has one.
+// `stk` (CUT_WORDS words, `stride` apart) holds the old list meanwhile.
+__host__ __device__ inline void cut_trim(const CutArgs& a, const int tile, uint32_t* const stk, const int stride) {
+    uint32_t* const out = a.cuts + (size_t)tile * CUT_WORDS;
+    const uint32_t hdr = out[0];
+    if (!(hdr & CUT_VALID)) return;
+    const int n = (int)(hdr & 0xffu);
+    const int kinds = (int)((hdr >> 8) & 0x3fu);
+    if ((kinds & 3) == 2 && ((kinds >> 2) & 3) == 2 && ((kinds >> 4) & 3) == 2) return;  // no sign-keeping axis
+    const int tix = tile % a.tiles_x, tiy = tile / a.tiles_x;
+    double dd[4][3];
+    cut_corner_rays(a, tix, tiy, dd);
+    double ddmax = 0.0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        ddmax = __builtin_fmax(ddmax, (__builtin_fabs(dd[c][0]) + __builtin_fabs(dd[c][1])) + __builtin_fabs(dd[c][2]));
+    const double slack = 1e-9 * ddmax + 4.0 * (0x1p-50 * a.mag);
+    if (!(slack < 1e100)) return;
+    for (int i = 0; i < n; ++i) stk[i * stride] = out[1 + i];
+    int w = 0;
+    for (int i = 0; i < n; ++i) {
+        const uint32_t e = stk[i * stride];
+        const int rest = n - 1 - i;  // every later entry can do with one word
+        uint32_t leaf = 0u;
+        bool per_ray = false;
+        if (e & rt::DESC_LEAF) {
+            leaf = e;
+        } else if ((e & CUT_NODE) == CUT_NODE) {
+            const uint32_t d = a.nodes[e & CUT_NODE_IDX].desc;
+            if (d & rt::DESC_LEAF) {
+                leaf = d;
+                per_ray = true;
+            }
+        }
+        const uint32_t cnt = ((leaf >> 28) & 7u) + 1u;
+        if (leaf == 0u || cnt == 8u) {  // not a leaf, or one with its range in leaf_ext: as it is
+            out[1 + w++] = e;
+            continue;
+        }
+        const uint32_t first = leaf & rt::DESC_TRI_MASK;
+        const uint32_t live = cut_live_triangles(a.tris, first, cnt, dd, slack);
+        if (live == 0u) continue;
+        int lo = 0, hi = (int)cnt - 1;
+        while (!((live >> lo) & 1u)) ++lo;
+        while (!((live >> hi) & 1u)) --hi;
+        const uint32_t range = rt::DESC_LEAF | ((uint32_t)(hi - lo) << 28) | (first + (uint32_t)lo);
+        if (per_ray) {
+            if (lo == 0 && hi == (int)cnt - 1) {
+                out[1 + w++] = e;
+            } else if (w + 2 + rest <= CUT_CAP) {
+                out[1 + w++] = e | CUT_TRIM;
+                out[1 + w++] = range;
+            } else {
+                out[1 + w++] = e;
+            }
+            continue;
+        }
+        int runs = 0;
+        for (int m = lo; m <= hi; ++m) runs += ((live >> m) & 1u) && !(m > lo && ((live >> (m - 1)) & 1u));
+        if (runs > 1 && w + runs + rest <= CUT_CAP) {
+            int m = lo;
+            while (m <= hi) {
+                if (!((live >> m) & 1u)) {
+                    ++m;
+                    continue;
+                }
+                int m1 = m;
+                while (m1 + 1 <= hi && ((live >> (m1 + 1)) & 1u)) ++m1;
+                out[1 + w++] = rt::DESC_LEAF | ((uint32_t)(m1 - m) << 28) | (first + (uint32_t)m);
+                m = m1 + 1;
+            }
+        } else {
+            out[1 + w++] = range;
+        }
+    }
+    out[0] = (hdr & ~0xffu) | (uint32_t)w;
+}
+
 // One thread per block.  A wave takes an 8 x 8 patch of blocks (16 parents, neighbouring parts of the tree: its
 // loads hit each other's lines in the vector L1), a workgroup a row of four patches.
 __global__ __launch_bounds__(CUT_THREADS) void cut_level_kernel(const CutArgs a) {
@@ -1117,6 +1266,7 @@ __global__ __launch_bounds__(CUT_THREADS) void cut_level_kernel(const CutArgs a)
     const int tiles_y = a.n_tiles / a.tiles_x;
     if (tix >= a.tiles_x || tiy >= tiles_y) return;
     cut_refine(a, tiy * a.tiles_x + tix, s_stk + threadIdx.x, CUT_THREADS);
+    if (a.tris) cut_trim(a, tiy * a.tiles_x + tix, s_stk + threadIdx.x, CUT_THREADS);
 }
 
 // ---- the render kernels' side of the cuts (shared by the f64 and the fp32 packet kernels) ----

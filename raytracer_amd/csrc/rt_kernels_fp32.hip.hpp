@@ -281,9 +281,13 @@ __device__ __forceinline__ void trace_packet32(const Packet32Args& sc, const uns
                 }
             } else if ((cur & rtk::CUT_NODE_ENTRY) == rtk::CUT_NODE_ENTRY) {
                 // entry of a cut: a BLAS node whose own box is tested per ray
-                const uint32_t ni = cur & 0x1FFFFFFFu;
+                const uint32_t ni = cur & rtk::CUT_NODE_IDX;
                 cfptr q = (cfptr)(const void*)(sc.nodes + ni);
-                const uint32_t desc = ((rtk::cuptr)(const void*)(sc.nodes + ni))[6];
+                uint32_t desc = ((rtk::cuptr)(const void*)(sc.nodes + ni))[6];
+                if (cur & rtk::CUT_TRIM) {  // the leaf's live triangles: next word of the list (rtk::cut_trim)
+                    ++ei;
+                    desc = (uint32_t)__builtin_amdgcn_readlane((int)vlist, ei);
+                }
                 if (COUNT) wc.nodes += (unsigned)__builtin_popcountll(inm);
                 const unsigned long long hm = slab32<OCT>(q[0], q[1], q[2], q[3], q[4], q[5], ixy, izx, iyz) & inm;
                 if (hm != 0ull) {

@@ -16,21 +16,28 @@ from raytracer_amd import meshgen
 
 LEAF, TLAS, ROOT = 0x80000000, 0x40000000, 0x20000000
 NODE = TLAS | ROOT
+TRIM, NODE_IDX = 0x10000000, 0x03FFFFFF
 
 
 class Tree:
     """The host tree in the reference's numbering plus what maps device records back to it."""
 
-    def __init__(self, host):
+    def __init__(self, host, coords, timestep):
         self.tl = host.tlas()
         self.slots = [host.slot(s) for s in range(host.info.n_meshes)]
         self.roots = np.array([s["dev_root"] for s in self.slots])
+        pm, pe = host.prim_tables()
+        self.verts = np.stack([np.asarray(coords[m], np.float64)[timestep, e] for m, e in zip(pm, pe)])  # prim -> 3 x 3
 
     def locate(self, dev_idx):
         s = int(np.searchsorted(self.roots, dev_idx, side="right") - 1)
         i = int(dev_idx - self.roots[s])
         assert 0 <= i < len(self.slots[s]["left"]), (dev_idx, s, i)
         return s, i
+
+    def leaf_range(self, s, i):
+        sl = self.slots[s]
+        return int(sl["tri_base"] + sl["min_idx"][i]), int(sl["count"][i])
 
 
 def make_rays(cam, p00, sp, x0, x1, y0, y1, rng, n_random=6):
@@ -58,6 +65,23 @@ def slab(box, cam, inv):
         return (tmin <= tmax) & (tmax > 0.0) & (tmin < np.inf)
 
 
+def tri_hits(v, cam, d):
+    """One row of intersect_bvh_triangles (cpp/rtrayintersection.cpp:64-106) for all rays: hit or not."""
+    v0, e0, e2 = v[0], v[1] - v[0], v[2] - v[0]
+    px = d[:, 1] * e2[2] - d[:, 2] * e2[1]
+    py = d[:, 2] * e2[0] - d[:, 0] * e2[2]
+    pz = d[:, 0] * e2[1] - d[:, 1] * e2[0]
+    det = (e0[0] * px + e0[1] * py) + e0[2] * pz
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        inv = 1.0 / det
+        tv = cam - v0
+        u = ((tv[0] * px + tv[1] * py) + tv[2] * pz) * inv
+        q = np.array([tv[1] * e0[2] - tv[2] * e0[1], tv[2] * e0[0] - tv[0] * e0[2], tv[0] * e0[1] - tv[1] * e0[0]])
+        vv = ((d[:, 0] * q[0] + d[:, 1] * q[1]) + d[:, 2] * q[2]) * inv
+        t = ((e2[0] * q[0] + e2[1] * q[1]) + e2[2] * q[2]) * inv
+        return (det > 1e-6) & (u >= 0) & (u <= 1) & (vv >= 0) & (u + vv <= 1) & (t >= 0)
+
+
 def walk_blas(tree, s, i, mask, cam, inv, out, own_test=True):
     sl = tree.slots[s]
     if own_test:
@@ -65,7 +89,7 @@ def walk_blas(tree, s, i, mask, cam, inv, out, own_test=True):
     if not mask.any():
         return
     if sl["left"][i] < 0:
-        out.append((int(sl["tri_base"] + sl["min_idx"][i]), mask.copy()))
+        out.append((*tree.leaf_range(s, i), mask.copy()))
         return
     walk_blas(tree, s, int(sl["left"][i]), mask, cam, inv, out)
     walk_blas(tree, s, int(sl["left"][i]) + 1, mask, cam, inv, out)
@@ -85,16 +109,30 @@ def walk_tlas(tree, i, mask, cam, inv, out):
 
 
 def walk_cut(tree, entries, n_rays, cam, inv):
+    """-> [(first triangle, count, rays)] in the order the render kernel tests them."""
     out = []
     everyone = np.ones(n_rays, bool)
-    for e in entries:
-        e = int(e)
-        if e & LEAF:
+    entries = [int(e) for e in entries]
+    k = 0
+    while k < len(entries):
+        e = entries[k]
+        k += 1
+        if e & LEAF:  # a leaf every ray passes, or a run of its live triangles (cut_trim)
             assert ((e >> 28) & 7) != 7, "leaf_ext leaves are not used by these scenes"
-            out.append((e & 0x0FFFFFFF, everyone.copy()))
+            out.append((e & 0x0FFFFFFF, ((e >> 28) & 7) + 1, everyone.copy()))
         elif (e & NODE) == NODE:
-            s, i = tree.locate(e & 0x1FFFFFFF)
-            walk_blas(tree, s, i, everyone, cam, inv, out, own_test=True)
+            s, i = tree.locate(e & NODE_IDX)
+            if e & TRIM:  # a leaf tested per ray; the next word names its live triangles
+                r = entries[k]
+                k += 1
+                assert tree.slots[s]["left"][i] < 0 and (r & LEAF) and ((r >> 28) & 7) != 7
+                m = slab(tree.slots[s]["boxes"][i], cam, inv)
+                f, c = tree.leaf_range(s, i)
+                assert f <= (r & 0x0FFFFFFF) and (r & 0x0FFFFFFF) + ((r >> 28) & 7) + 1 <= f + c
+                if m.any():
+                    out.append((r & 0x0FFFFFFF, ((r >> 28) & 7) + 1, m))
+            else:
+                walk_blas(tree, s, i, everyone, cam, inv, out, own_test=True)
         elif e & TLAS:
             walk_tlas(tree, e & 0x3FFFFFFF, everyone, cam, inv, out)
         elif e & ROOT:
@@ -107,18 +145,19 @@ def walk_cut(tree, entries, n_rays, cam, inv):
 
 
 def per_ray(seq, n_rays):
-    return [tuple(leaf for leaf, m in seq if m[r]) for r in range(n_rays)]
+    return [[t for f, c, m in seq if m[r] for t in range(f, f + c)] for r in range(n_rays)]
 
 
 def check_scene(coords, colors, cam, H, W, spp, level, seed, timestep=0):
+    """-> blocks with a cut, entries, blocks, triangles the reference tests, triangles the cut walk tests."""
     host = ra.HostScene(coords, colors, timestep)
-    tree = Tree(host)
+    tree = Tree(host, coords, timestep)
     cam_c, p00, sp = (np.asarray(x, np.float64) for x in cam)
     words, tx, (lo, top) = ra.tile_cuts_host(host, cam_c, p00, sp, H, W, spp, level=level)
     assert lo <= level <= top
     ts = 1 << level
     rng = np.random.default_rng(seed)
-    n_valid = n_entries = 0
+    n_valid = n_entries = n_ref = n_cut = 0
     for b in range(words.shape[0]):
         hdr = int(words[b, 0])
         if not hdr >> 31:
@@ -138,13 +177,31 @@ def check_scene(coords, colors, cam, H, W, spp, level, seed, timestep=0):
             elif kind == 1:
                 assert (inv[:, a] < 0).all() and (inv[:, a] > -1e100).all(), (b, a)
         tame = (np.abs(inv) < 1e100).all(axis=1)  # the kernel walks batches with other rays from the root
-        ref, cut = [], []
+        ref = []
         walk_tlas(tree, 0, tame.copy(), cam_c, inv, ref)
         got = walk_cut(tree, words[b, 1:1 + n], len(tame), cam_c, inv)
-        cut = [(leaf, m & tame) for leaf, m in got]
-        assert per_ray(cut, len(tame)) == per_ray(ref, len(tame)), (b, [hex(int(x)) for x in words[b, :1 + n]])
+        cut = [(f, c, m & tame) for f, c, m in got]
+        want, have = per_ray(ref, len(tame)), per_ray(cut, len(tame))
+        for r in range(len(tame)):
+            # the cut walk tests the triangles the reference tests, in its order, but for some that this ray misses
+            # by the reference's own arithmetic
+            it = iter(want[r])
+            dropped = []
+            for t in have[r]:
+                for w in it:
+                    if w == t:
+                        break
+                    dropped.append(w)
+                else:
+                    pytest.fail(f"block {b} ray {r}: triangle {t} out of order / not in the reference's walk: "
+                                f"{[hex(int(x)) for x in words[b, :1 + n]]}")
+            dropped.extend(it)
+            for t in dropped:
+                assert not tri_hits(tree.verts[t], cam_c, d[r:r + 1])[0], (b, r, t)
+            n_ref += len(want[r])
+            n_cut += len(have[r])
     host.close()
-    return n_valid, n_entries, words.shape[0]
+    return n_valid, n_entries, words.shape[0], n_ref, n_cut
 
 
 def two_meshes():
@@ -162,7 +219,7 @@ def test_cut_walk_equals_root_walk_two_meshes_rotated_camera(level, monkeypatch)
     for ci, cam in enumerate([meshgen.camera_arrays(W, H),
                               meshgen.camera_arrays(W, H, center=(0.3, 0.1, 0.2), target=(0, 0, -2), fov=70),
                               meshgen.camera_arrays(W, H, center=(3.0, 2.0, 1.0), target=(0.4, 0.3, -2.5), fov=50)]):
-        n_valid, n_entries, n_blocks = check_scene(coords, colors, cam, H, W, 64, level, seed=ci, timestep=1)
+        n_valid, n_entries, n_blocks, _, _ = check_scene(coords, colors, cam, H, W, 64, level, seed=ci, timestep=1)
         assert n_valid == n_blocks  # mixed-sign blocks get cuts too
 
 
@@ -233,3 +290,22 @@ def test_cuts_prune_most_of_the_tree():
     n = words[:, 0] & 0xff
     assert (words[:, 0] >> 31).all() and n.mean() < 6 and host.info.n_blas_nodes > 1500
     host.close()
+
+
+def test_trimmed_leaves_drop_triangles_and_only_sure_misses(monkeypatch):
+    """cut_trim: at the finest level the lists name the leaves' live triangles.  check_scene asserts that every
+    triangle the cut walk skips is one the ray misses by the reference's own arithmetic; here also that trimming
+    does something, and that RT_NO_TRIM=1 gives the untrimmed lists (every triangle of the reference's walk)."""
+    c, k = meshgen.plate(40, sway=0.2)
+    c1, k1 = meshgen.uv_sphere(12, 16, radius=0.8, center=(0.2, 0.1, -1.5))  # closed surface: back faces
+    H = W = 48
+    cam = meshgen.camera_arrays(W, H, center=(0.1, 0.05, 0.4), target=(0.0, 0.0, -2.0), fov=60)
+    _, _, _, n_ref, n_cut = check_scene([c, c1], [k, k1], cam, H, W, 64, 1, seed=11)
+    assert n_cut < 0.7 * n_ref, (n_ref, n_cut)
+    monkeypatch.setenv("RT_NO_TRIM", "1")
+    _, _, _, n_ref2, n_cut2 = check_scene([c, c1], [k, k1], cam, H, W, 64, 1, seed=11)
+    assert n_ref2 == n_ref and n_cut2 == n_ref
+    monkeypatch.delenv("RT_NO_TRIM")
+    monkeypatch.setenv("RT_CUT_LO", "0")  # per-pixel blocks
+    _, _, _, n_ref0, n_cut0 = check_scene([c, c1], [k, k1], cam, H, W, 64, 0, seed=12)
+    assert n_cut0 < 0.6 * n_ref0, (n_ref0, n_cut0)
