@@ -231,6 +231,15 @@ struct rt_ctx {
         int states_n = 0;
     } slot[2];
     int last_slot = 0;
+    // Streams of the look-ahead fills of very large frames (>= 2^30 words), learnt from the last launch of the same
+    // shape: as few as keep the sampler (jumps + jitter kernel, timed while it overlapped that launch's traversal)
+    // within 0.8 of the traversal kernel's time; 0: not learnt yet (the default plan, 1024 streams).
+    int adapt_n = 0;
+    int adapt_rows = 0, adapt_w = 0, adapt_spp = 0;
+    // a new count needs new jump polynomials (~20 ms of host work): a helper thread computes them into the host
+    // cache while frames go on with the old count, which gives way once they are there
+    std::future<void> adapt_job;
+    int adapt_pending_n = 0, adapt_pending_rows = 0, adapt_pending_w = 0, adapt_pending_spp = 0;
     bool have_last_start = false;
     uint64_t last_start = 0;
     DevBuf<uint32_t> d_states;  // rt_rng_jitter only
@@ -323,7 +332,7 @@ struct StreamPlan {
     uint64_t total_words = 0;  // rows*W*spp*4 (the last stream stops there)
 };
 
-StreamPlan plan_streams(int rows, int W, int spp, int frames = 1) {
+StreamPlan plan_streams(int rows, int W, int spp, int frames = 1, int hidden_n = 0) {
     StreamPlan p;
     // One workgroup per stream.  Measured: a stream regenerates 624 words in ~1.2 us (a chain of dependent
     // LDS round trips), i.e. ~1.9 ns/word, and one jump costs ~1.2 us of the whole GPU.  The traversal kernel
@@ -339,6 +348,10 @@ StreamPlan plan_streams(int rows, int W, int spp, int frames = 1) {
     // is hidden behind the traversal either way, and its instruction count is the same), but the FIRST frame of
     // a job waits for its sampler: 4096^2 x 64 spp, 14.8 ms with 256 streams, 5.8 ms with 1024.
     target = std::max<uint64_t>(target, std::min<uint64_t>(1024, words >> 22));
+    // ... and a look-ahead fill of such a frame, which nobody waits for, takes the number the context has learnt
+    // (adapt_streams below): the sampler's workgroups hold wave slots the traversal kernel would use, so it should
+    // run on as few as still finish well before the traversal it hides behind
+    if (hidden_n > 0 && (words >> 30) != 0) target = (uint64_t)hidden_n;
     if (const char* e = std::getenv("RT_JITTER_STREAMS")) target = (uint64_t)std::max(1, std::atoi(e));
     uint64_t stride = (words + target - 1) / target;
     stride = (stride + 623) / 624 * 624;
@@ -402,6 +415,9 @@ int dev_stream_states(rt_ctx* c, uint32_t* states, int n, uint64_t stride) {
     if (n > 1) HIP_TRY(hipMemsetAsync(states + rt::MT_N, 0, size_t(n - 1) * sizeof(rt::MtState), c->rng_stream));
     int levels = 0;
     while ((1 << levels) < n) ++levels;
+    // host polynomials in ascending order: each is one squaring of the one before (the tree uses them top down)
+    for (int k = 0; k < levels; ++k)
+        if (c->d_polys.find(stride << k) == c->d_polys.end()) (void)rt::mt_jump_poly(stride << k);  // may throw
     for (int k = levels - 1; k >= 0; --k) {
         const int step = 1 << k;
         const unsigned long long* poly = nullptr;
@@ -436,13 +452,13 @@ int sync_state(rt_ctx* c) {
 
 // Generate the jitter of `frames` consecutive launches (rows x W x spp samples each, the first one starting `ahead`
 // words after the context's current position) into slot `k`, entirely on rng_stream.
-int fill_slot(rt_ctx* c, int k, uint64_t ahead, int rows, int W, int spp, int frames = 1) {
+int fill_slot(rt_ctx* c, int k, uint64_t ahead, int rows, int W, int spp, int frames = 1, int hidden_n = 0) {
     rt_ctx::JitterSlot& sl = c->slot[k];
     sl.valid = false;
     const size_t n_smp = size_t(rows) * size_t(W) * size_t(spp) * size_t(frames);
     int rc = sl.buf.ensure(n_smp * 2);
     if (rc) return rc;
-    const StreamPlan pl = plan_streams(rows, W, spp, frames);
+    const StreamPlan pl = plan_streams(rows, W, spp, frames, hidden_n);
     if ((rc = sl.d_states.ensure(size_t(pl.n) * rt::MT_N))) return rc;
     if ((rc = sl.d_end.ensure(rt::MT_N))) return rc;
     const double t0 = now_ms();
@@ -859,6 +875,7 @@ void rt_destroy(rt_ctx* c) {
     c->leaf_ext.release();
     c->tris.release();
     c->colors.release();
+    if (c->adapt_job.valid()) c->adapt_job.wait();
     if (c->prep_stream) (void)hipStreamSynchronize(c->prep_stream);
     for (auto& cs : c->cam) {
         cs.nodes.release();
@@ -1271,6 +1288,50 @@ int launch_packet(rt_ctx* c, const rt_render_params* p, int tile_log2, int tiles
     return launch_packet_kernel(c, p, tile_log2, tiles_x, n_tiles, pb, pp, cuts_made);
 }
 
+// Called when the previous launch is known to be complete (its kernel time resolved): learn the stream count of
+// the look-ahead fills of very large frames from that launch's sampler and traversal times (see rt_ctx::adapt_n).
+void adapt_streams(rt_ctx* c, int rows, int W, int spp) {
+    if (std::getenv("RT_NO_ADAPT_STREAMS") || std::getenv("RT_JITTER_STREAMS")) return;  // (tuning knobs)
+    if (!c->kernel_ms_known || !c->jitter_timed || c->out_rows != rows || c->out_w != W || c->out_spp != spp) return;
+    if (((uint64_t(rows) * uint64_t(W) * uint64_t(spp) * 4u) >> 30) == 0) return;
+    const rt_ctx::JitterSlot& sl = c->slot[c->last_slot];  // the slot that launch read: its fill is complete
+    if (sl.rows != rows || sl.W != W || sl.spp != spp || sl.frames != 1 || sl.states_n < 1) return;
+    float sampler_ms = 0.f;
+    if (hipEventElapsedTime(&sampler_ms, sl.t0, sl.t1) != hipSuccess) {
+        (void)hipGetLastError();
+        return;
+    }
+    const double render_ms = c->stats.render_kernel_ms;
+    if (!(sampler_ms > 0.f) || !(render_ms > 0.0)) return;
+    double want = double(sl.states_n) * double(sampler_ms) / (0.8 * render_ms);
+    want = std::min(1024.0, std::max(256.0, std::ceil(want / 64.0) * 64.0));
+    if (c->adapt_job.valid()) {
+        if (c->adapt_job.wait_for(std::chrono::seconds(0)) != std::future_status::ready) return;
+        try {
+            c->adapt_job.get();
+            c->adapt_n = c->adapt_pending_n;
+            c->adapt_rows = c->adapt_pending_rows;
+            c->adapt_w = c->adapt_pending_w;
+            c->adapt_spp = c->adapt_pending_spp;
+        } catch (const std::exception&) {  // no new polynomials: the old count stays
+        }
+        return;  // (the next launch measures the new count before anything else is decided)
+    }
+    const int cur = (c->adapt_n > 0 && c->adapt_rows == rows && c->adapt_w == W && c->adapt_spp == spp) ? c->adapt_n : sl.states_n;
+    if (want < 0.8 * cur || want > 1.25 * cur) {  // (hysteresis: a new count costs a tree of jumps)
+        const StreamPlan pl = plan_streams(rows, W, spp, 1, (int)want);
+        c->adapt_pending_n = (int)want;
+        c->adapt_pending_rows = rows;
+        c->adapt_pending_w = W;
+        c->adapt_pending_spp = spp;
+        c->adapt_job = std::async(std::launch::async, [pl]() {
+            int levels = 0;
+            while ((1 << levels) < pl.n) ++levels;
+            for (int k = 0; k < levels; ++k) (void)rt::mt_jump_poly(pl.stride << k);
+        });
+    }
+}
+
 // rt_render.  `pipelined` (rt_render_scene only, plain MT19937 frames without per-sample outputs): the
 // launch is enqueued behind the previous one instead of waiting for it, so the GPU goes from frame to
 // frame without a gap while the host reads the previous frame back.  Everything a launch touches is
@@ -1312,7 +1373,9 @@ int render_impl(rt_ctx* c, const rt_render_params* p, bool pipelined) {
     PacketPrep pp;
     rt_ctx::CamSet* cs = nullptr;
     CutPlan cp;
-    const bool overlap = std::getenv("RT_NO_PREP_OVERLAP") == nullptr;  // (comparison knob, read per launch)
+    // (small frames of small scenes: the two cross-stream dependencies cost more than the ~10 us of prep they hide)
+    const bool overlap = std::getenv("RT_NO_PREP_OVERLAP") == nullptr &&  // (comparison knob, read per launch)
+                         (n_smp >= (size_t(1) << 24) || c->n_tris >= (1 << 18));
     if (packet_launch) {
         c->cam_idx ^= 1;
         cs = &c->cam[c->cam_idx];
@@ -1340,6 +1403,7 @@ int render_impl(rt_ctx* c, const rt_render_params* p, bool pipelined) {
         // rt_render calls can be timed launch by launch without a stats call (and its sync) in between
         int trc = resolve_kernel_ms(c);
         if (trc) return trc;
+        adapt_streams(c, rows, W, spp);
     }
     // the other samplers write slot 0's buffer on the traversal stream: no look-ahead fill may be using it.  (MT19937
     // launches need no such wait: everything they touch of the sampler is ordered on rng_stream or guarded by the
@@ -1605,7 +1669,8 @@ int render_impl(rt_ctx* c, const rt_render_params* p, bool pipelined) {
             const int other = 1 - use;
             // slot `other` was last read by an earlier call's kernel: fill_slot makes rng_stream wait
             // for it (read_done); the slot's own jitter kernel is ordered on rng_stream.
-            if (!covered && (rc = fill_slot(c, other, target - c->pos, rows, W, spp, group))) return rc;
+            const int hidden_n = (c->adapt_n > 0 && c->adapt_rows == rows && c->adapt_w == W && c->adapt_spp == spp) ? c->adapt_n : 0;
+            if (!covered && (rc = fill_slot(c, other, target - c->pos, rows, W, spp, group, hidden_n))) return rc;
         } catch (const std::exception&) {
             c->slot[1 - use].valid = false;
         }

@@ -7,6 +7,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <vector>
 #include <stdexcept>
 #include <thread>
 
@@ -127,17 +128,44 @@ void sqr_mod(MtPoly& r) {
         t[2 * k] = lo;
         t[2 * k + 1] = hi;
     }
-    const Phi& f = phi();
-    for (int i = 2 * (kDeg - 1); i >= kDeg; --i) {
-        if (!poly_bit(t, i)) continue;
+    // Reduction mod phi, eight bits at a time from the top: red[v] is the multiple q(x) phi(x), deg q < 8, whose
+    // bits kDeg .. kDeg+7 spell v, so XORing it in at the right shift clears a whole byte above the degree.
+    constexpr int kRedWords = kPolyWords + 1;  // kDeg + 8 bits
+    static std::vector<uint64_t> red;
+    static std::once_flag red_once;
+    std::call_once(red_once, [] {
+        const Phi& f = phi();
+        red.assign(size_t(256) * kRedWords, 0);
+        for (int v = 0; v < 256; ++v) {
+            uint64_t* q = red.data() + size_t(v) * kRedWords;
+            for (int b = 7; b >= 0; --b) {
+                const bool have = poly_bit(q, kDeg + b);
+                if (have == (((v >> b) & 1) != 0)) continue;
+                for (int k = 0; k < kPolyWords; ++k) {  // q ^= phi << b  (phi has kDeg + 1 bits, kPolyWords words)
+                    q[k] ^= f.b[k] << b;
+                    if (b) q[k + 1] ^= f.b[k] >> (64 - b);
+                }
+            }
+        }
+    });
+    const int top = kDeg + ((2 * (kDeg - 1) - kDeg) / 8) * 8;  // lowest bit of the highest byte above the degree
+    for (int i = top; i >= kDeg; i -= 8) {
+        const int w = i / 64, o = i % 64;
+        unsigned v = unsigned(t[w] >> o);
+        if (o > 56) v |= unsigned(t[w + 1] << (64 - o));
+        v &= 0xffu;
+        if (!v) continue;
+        const uint64_t* q = red.data() + size_t(v) * kRedWords;
         const int sh = i - kDeg, ws = sh / 64, bs = sh % 64;
         if (bs == 0) {
-            for (int k = 0; k < kPolyWords; ++k) t[k + ws] ^= f.b[k];
+            for (int k = 0; k < kRedWords; ++k) t[k + ws] ^= q[k];
         } else {
-            for (int k = 0; k < kPolyWords; ++k) {
-                t[k + ws] ^= f.b[k] << bs;
-                t[k + ws + 1] ^= f.b[k] >> (64 - bs);
+            uint64_t carry = 0;
+            for (int k = 0; k < kRedWords; ++k) {
+                t[k + ws] ^= (q[k] << bs) | carry;
+                carry = q[k] >> (64 - bs);
             }
+            t[kRedWords + ws] ^= carry;
         }
     }
     std::memcpy(r.b, t, sizeof(r.b));
