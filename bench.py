@@ -439,8 +439,25 @@ def main():
                             "the blocks' cuts and fetches fewer node records than this"}
         # (3) what binds: fp64 VALU issue.  Instruction count from the committed PMC pass of THESE kernels
         #     (source hash must match), time from this run.
+        # the same kernel with the GPU to itself (no look-ahead sampler, prep / cut kernels in front of it instead of
+        # beside the previous launch): what the sharing in the timed steps costs it
+        alone_ms = None
+        try:
+            os.environ["RT_NO_LOOKAHEAD"] = "1"
+            os.environ["RT_NO_PREP_OVERLAP"] = "1"
+            al = []
+            for _ in range(3):
+                frame(0)
+                ctx.sync()
+                al.append(ctx.stats()["render_kernel_ms"])
+            alone_ms = float(np.mean(al[1:]))
+        finally:
+            os.environ.pop("RT_NO_LOOKAHEAD", None)
+            os.environ.pop("RT_NO_PREP_OVERLAP", None)
         traffic = None
         lane_ops = None
+        step_ops = None
+        step_kernels = None
         pmc_note = None
         pmc_path = os.path.join(ROOT, "profiles", f"pmc_{args.workload}.json")
         if os.path.exists(pmc_path):
@@ -456,6 +473,19 @@ def main():
                     traffic = pmc.get("hbm_bytes_per_launch")
                     vi = pmc.get(pmc.get("dominant_kernel", ""), {}).get("SQ_INSTS_VALU")
                     lane_ops = vi * 64 if vi else None
+                    # every kernel of a steady-state step (they share the GPU with each other): launches per step x
+                    # SQ_INSTS_VALU per launch
+                    per_step = {"render_packet_kernel": 1, "mt_jitter_kernel": 1, "mt_jump_all_kernel": 1,
+                                "mt_jump_kernel": 1, "prep_frame_kernel": 1,
+                                "cut_level_kernel": 1}  # (the summary keeps the finest level's launch; the coarser one is ~1/16 of it)
+                    step_kernels = {}
+                    for name, rec in pmc.items():
+                        if not isinstance(rec, dict) or "SQ_INSTS_VALU" not in rec or "<true" in name:
+                            continue
+                        for key, mult in per_step.items():
+                            if key in name:
+                                step_kernels[key] = rec["SQ_INSTS_VALU"] * 64.0 * mult
+                    step_ops = sum(step_kernels.values()) if step_kernels else None
                     pmc_note = f"profiles/pmc_{args.workload}.json (SQ_INSTS_VALU x 64; FETCH_SIZE/WRITE_SIZE passes)"
             except Exception as e:
                 pmc_note = f"profiles/pmc_{args.workload}.json unreadable: {e}"
@@ -469,6 +499,16 @@ def main():
                     "kernel_ms_source": ("HIP events of the %d timed launches" % args.steps) if kernel_ms_timed
                     else "HIP events of one launch after the timed loop",
                     "lane_ops_per_launch": lane_ops, "counters_from": pmc_note,
+                    "note": "kernel_ms is the kernel's duration in the timed steps, where it shares the GPU with the next "
+                            "frame's sampler, prep and cut kernels (all VALU work): kernel_alone is the same kernel with "
+                            "the GPU to itself, gpu_step counts every kernel of a step against the step's time",
+                    "kernel_alone": {"kernel_ms": alone_ms,
+                                     "achieved": lane_ops / (alone_ms * 1e-3) / 1e12 if lane_ops and alone_ms else None,
+                                     "frac": lane_ops / (alone_ms * 1e-3) / FP64_LANE_OPS_PEAK if lane_ops and alone_ms else None},
+                    "gpu_step": {"lane_ops_per_step": step_ops, "by_kernel": step_kernels,
+                                 "ms_per_step": elapsed / args.steps * 1e3,
+                                 "achieved": step_ops / (elapsed / args.steps) / 1e12 if step_ops else None,
+                                 "frac": step_ops / (elapsed / args.steps) / FP64_LANE_OPS_PEAK if step_ops else None},
                     "peak_note": "256 CU x 4 SIMD x 16 lanes x 2.4 GHz, no fma (-ffp-contract=off is the parity contract)",
                     "rays_per_launch": rays_per_frame, "kernel_only_mrays_s": rays_per_frame / (kms * 1e-3) / 1e6,
                     "nodes_per_ray": cs["nodes_visited"] / rays, "tris_per_ray": cs["tris_tested"] / rays,
@@ -604,7 +644,7 @@ def main():
                        "sampler": "MT19937 reference stream (GPU GF(2) jump-ahead + jitter kernels, device-resident state)",
                        "hit_ids_written": want_ids, "frames_per_step_per_gpu": 1,
                        "cuts": ("off (RT_NO_CUT)" if os.environ.get("RT_NO_CUT") else
-                                "made per frame for frames >= %g rays" % float(os.environ.get("RT_CUT_MIN_RAYS", 64e6))),
+                                "made per frame for frames >= %g rays" % float(os.environ.get("RT_CUT_MIN_RAYS", 12e6))),
                        "host_threads_per_rank": int(ra.lib.rt_host_threads()),
                        "parallelism": f"frame-sharded x{world}, no collective"},
             "roofline": roofline,

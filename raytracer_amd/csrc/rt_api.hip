@@ -1143,10 +1143,11 @@ int make_cuts(rt_ctx* c, hipStream_t st, const rt_render_params* p, int tile_log
     out = CutTables{};
     const int W = p->image_width, spp = p->samples, rows = p->row_end - p->row_begin;
     const bool no_cut = std::getenv("RT_NO_CUT") != nullptr;  // (comparison / test knob, read per launch)
-    // The cut kernels are chains of dependent steps (~0.3 ms however small the image) and save about a third of the
-    // traversal: they pay from a few ms of traversal on.  Measured break-even: ~30 M rays (1024 x 576 x 50).
+    // The cut kernels are chains of dependent steps (~0.3 ms however small the image) and save a third to a half of
+    // the traversal.  Measured: 2048^2 x 4 spp (16.7 M rays, 1 M triangles) 1.47 -> 1.32 ms per frame with cuts,
+    // 400 x 225 x 50 spp (4.5 M rays) 0.30 -> 0.49 ms.
     const char* mr = std::getenv("RT_CUT_MIN_RAYS");  // (tuning knob)
-    const double min_rays = mr ? std::atof(mr) : 64e6;
+    const double min_rays = mr ? std::atof(mr) : 12e6;
     if (!cuts || !allowed || no_cut || double(rows) * W * spp < min_rays) return RT_OK;
     const CutPlan cp = plan_cuts(W, rows, spp, tile_log2);
     rtk::CutArgs ca;
@@ -1529,9 +1530,10 @@ int render_impl(rt_ctx* c, const rt_render_params* p, bool pipelined) {
             if ((rc = cs->nodes.ensure(c->n_nodes))) return rc;
             if ((rc = cs->tlas.ensure(c->n_tlas))) return rc;
             if ((rc = cs->cuts.ensure(size_t(cp.total_words)))) return rc;
-            launch_prep(c, c->stream, cs->nodes.p, cs->tlas.p, nullptr, ox, oy, oz);
+            if ((rc = cs->tris.ensure((size_t)c->n_tris))) return rc;  // (f64 records: the cuts' triangle trimming)
+            launch_prep(c, c->stream, cs->nodes.p, cs->tlas.p, cs->tris.p, ox, oy, oz);
             const bool tame = (c->max_abs_coord + std::fabs(ox) + std::fabs(oy) + std::fabs(oz)) < 1e30;
-            if ((rc = make_cuts(c, c->stream, p, tile_log2, h_frame_params, cs->nodes.p, cs->tlas.p, nullptr, cs->cuts.p,
+            if ((rc = make_cuts(c, c->stream, p, tile_log2, h_frame_params, cs->nodes.p, cs->tlas.p, cs->tris.p, cs->cuts.p,
                                 !count && tame, ct)))
                 return rc;
             c->cut_plan = cp;

@@ -11,7 +11,7 @@ if TESTS not in sys.path:
     sys.path.insert(0, TESTS)
 
 
-# The cuts are made for frames of >= 64 M rays by default; the suites render far smaller frames, so
+# The cuts are made for frames of >= 12 M rays by default; the suites render far smaller frames, so
 # here every frame gets them -- every parity test then also tests the cuts.  (tests that want the default unset it)
 os.environ.setdefault("RT_CUT_MIN_RAYS", "0")
 

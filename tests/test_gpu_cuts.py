@@ -139,7 +139,7 @@ def test_gpu_cuts_equal_the_host_twin_word_for_word(ctx, monkeypatch):
 
 
 def test_small_frames_get_no_cuts_by_default(ctx, monkeypatch):
-    """The cut kernels cost ~0.3 ms whatever the image: by default only frames of >= 64 M rays get them."""
+    """The cut kernels cost ~0.3 ms whatever the image: by default only frames of >= 12 M rays get them."""
     monkeypatch.delenv("RT_CUT_MIN_RAYS")
     c0, k0 = meshgen.plate(16)
     host = ra.HostScene([c0], [k0], 0)
