@@ -1375,7 +1375,7 @@ static_assert((PACKET_STACK - PAIR64_STACK) * 16 >= 3 * 64 * 8, "the second pixe
 // test and the base of its sample index are wave-uniform (scalar unit), divisions by spp disappear, and the
 // per-pixel sums are done two pixels at a time.
 template <bool COUNT, bool P64>
-__global__ __launch_bounds__(NT, 8) void render_packet_kernel(const PacketArgs a) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 8), amdgpu_num_vgpr(64), amdgpu_num_sgpr(94))) void render_packet_kernel(const PacketArgs a) {
     __shared__ uint4 s_wstk[NT / 64][PACKET_STACK];
     __shared__ double s_col[NT / 64][3][64];
     __shared__ double s_acc[NT / 64][3][64];
