@@ -249,6 +249,10 @@ struct rt_ctx {
     DevBuf<uint8_t> rgb;
     DevBuf<int32_t> hit_prim;
     DevBuf<unsigned long long> counters;
+    // a frame whose jitter slot would exceed the budget is rendered band by band (render_frame): whole-frame outputs
+    DevBuf<double> frame_intensity, frame_hit_t;
+    DevBuf<uint8_t> frame_rgb;
+    DevBuf<int32_t> frame_hit_prim;
     unsigned long long* stats_counters = nullptr;  // where the last launch's visit counters are (or null)
     unsigned char* static_scratch = nullptr;       // this GPU's copy of the file-scope `scratch` (rt_render_static)
     DevBuf<uint32_t> gstack;
@@ -905,6 +909,10 @@ void rt_destroy(rt_ctx* c) {
         if (sl.t1) (void)hipEventDestroy(sl.t1);
         if (sl.read_done) (void)hipEventDestroy(sl.read_done);
     }
+    c->frame_intensity.release();
+    c->frame_hit_t.release();
+    c->frame_rgb.release();
+    c->frame_hit_prim.release();
     c->intensity.release();
     c->hit_t.release();
     c->rgb.release();
@@ -1682,6 +1690,95 @@ int render_impl(rt_ctx* c, const rt_render_params* p, bool pipelined) {
     return RT_OK;
 }
 
+// Rows per band when a launch's jitter slot (16 B per sample, two slots per context) would exceed the budget
+// (RT_JITTER_SLOT_BYTES, default 32 GiB), else 0: the launch is rendered in one piece.
+int band_rows_for(const rt_render_params* p) {
+    if (!p || p->sampler == RT_SAMPLER_EXPLICIT) return 0;  // (the caller's array: the caller bands)
+    const int W = p->image_width, spp = p->samples, rows = p->row_end - p->row_begin;
+    if (W < 1 || spp < 1 || rows < 16) return 0;
+    double budget = 32.0 * 1024.0 * 1024.0 * 1024.0;
+    if (const char* e = std::getenv("RT_JITTER_SLOT_BYTES")) budget = std::max(1.0, std::atof(e));
+    const double row_bytes = double(W) * spp * 16.0;
+    if (double(rows) * row_bytes <= budget) return 0;
+    const int64_t fit = (int64_t)(budget / row_bytes);
+    const int band = (int)std::max<int64_t>(8, fit / 8 * 8);
+    return band < rows ? band : 0;
+}
+
+// rt_render of any size: a launch whose jitter would not fit the budget is rendered as consecutive row bands -- the
+// same machinery as the multi-GPU bands: band after band at consecutive stream positions, the same frame bit for
+// bit -- each band's outputs copied (device to device, on the traversal stream) into whole-frame buffers that then
+// take the place of the context's output buffers.  The look-ahead sampler works across bands as it does across
+// frames.  Waits for the last band (the bands' kernel times and counters are summed for rt_last_stats).
+int render_frame(rt_ctx* c, const rt_render_params* p, bool pipelined) {
+    const int band = c && c->have_scene ? band_rows_for(p) : 0;
+    if (band == 0) return render_impl(c, p, pipelined);
+    const int H = p->image_height, W = p->image_width, spp = p->samples;
+    if (H < 1 || p->row_begin < 0 || p->row_end > H) return render_impl(c, p, pipelined);  // (reports the error)
+    const int rows = p->row_end - p->row_begin;
+    const size_t n_pix = size_t(rows) * size_t(W), n_smp = n_pix * size_t(spp);
+    HIP_TRY(hipSetDevice(c->device));
+    int rc;
+    if ((rc = c->frame_intensity.ensure(n_pix))) return rc;
+    if ((rc = c->frame_rgb.ensure(n_pix * 3))) return rc;
+    if ((p->flags & RT_FLAG_HIT_IDS) && (rc = c->frame_hit_prim.ensure(n_smp))) return rc;
+    if ((p->flags & RT_FLAG_HIT_T) && (rc = c->frame_hit_t.ensure(n_smp))) return rc;
+    const bool count = (p->flags & RT_FLAG_COUNTERS) != 0;
+    unsigned long long sums[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double jitter_ms = 0.0, host_jump_ms = 0.0;
+    // (the kernel time of a launch still pending from an earlier call belongs to that call)
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if ((rc = resolve_kernel_ms(c))) return rc;
+    const double k0 = c->kernel_ms_total;
+    for (int r = p->row_begin; r < p->row_end; r += band) {
+        rt_render_params q = *p;
+        q.row_begin = r;
+        q.row_end = std::min(r + band, p->row_end);
+        if ((rc = render_impl(c, &q, false))) return rc;
+        const size_t pix0 = size_t(r - p->row_begin) * size_t(W), pix_b = size_t(q.row_end - r) * size_t(W);
+        HIP_TRY(hipMemcpyAsync(c->frame_intensity.p + pix0, c->intensity.p, pix_b * sizeof(double), hipMemcpyDeviceToDevice,
+                               c->stream));
+        HIP_TRY(hipMemcpyAsync(c->frame_rgb.p + pix0 * 3, c->rgb.p, pix_b * 3, hipMemcpyDeviceToDevice, c->stream));
+        if (p->flags & RT_FLAG_HIT_IDS)
+            HIP_TRY(hipMemcpyAsync(c->frame_hit_prim.p + pix0 * spp, c->hit_prim.p, pix_b * spp * sizeof(int32_t),
+                                   hipMemcpyDeviceToDevice, c->stream));
+        if (p->flags & RT_FLAG_HIT_T)
+            HIP_TRY(hipMemcpyAsync(c->frame_hit_t.p + pix0 * spp, c->hit_t.p, pix_b * spp * sizeof(double),
+                                   hipMemcpyDeviceToDevice, c->stream));
+        if (count || r + band >= p->row_end) {  // counters are per launch: read them band by band
+            rt_stats st;
+            if ((rc = rt_last_stats(c, &st))) return rc;
+            sums[0] += st.nodes_visited;
+            sums[1] += st.tris_tested;
+            sums[2] += st.rays_hit;
+            sums[3] += st.wave_node_fetches;
+            sums[4] += st.wave_tri_fetches;
+            jitter_ms += st.jitter_kernel_ms;
+        }
+        host_jump_ms += c->stats.host_jump_ms;
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    std::swap(c->intensity, c->frame_intensity);
+    std::swap(c->rgb, c->frame_rgb);
+    if (p->flags & RT_FLAG_HIT_IDS) std::swap(c->hit_prim, c->frame_hit_prim);
+    if (p->flags & RT_FLAG_HIT_T) std::swap(c->hit_t, c->frame_hit_t);
+    c->out_rows = rows;
+    c->stats.rays = n_smp;
+    c->stats.render_kernel_ms = c->kernel_ms_total - k0;
+    c->stats.jitter_kernel_ms = jitter_ms;
+    c->stats.host_jump_ms = host_jump_ms;
+    if (count) {
+        c->stats.nodes_visited = sums[0];
+        c->stats.tris_tested = sums[1];
+        c->stats.rays_hit = sums[2];
+        c->stats.wave_node_fetches = sums[3];
+        c->stats.wave_tri_fetches = sums[4];
+    }
+    c->stats_counters = nullptr;  // (already summed)
+    c->timing_pending = false;
+    return RT_OK;
+}
+
 // rt_render_scene: the frame of the launch BEFORE the last one (pipelined launches), read back on the
 // copy stream while the last launch is still running
 int download_prev_rgb(rt_ctx* c, uint8_t* rgb, size_t n_bytes) {
@@ -1695,7 +1792,7 @@ int download_prev_rgb(rt_ctx* c, uint8_t* rgb, size_t n_bytes) {
 
 extern "C" {
 
-int rt_render(rt_ctx* c, const rt_render_params* p) { return render_impl(c, p, false); }
+int rt_render(rt_ctx* c, const rt_render_params* p) { return render_frame(c, p, false); }
 
 // rt_render for callers that cannot allocate: same prep + traversal kernels, the camera-relative records and
 // the counters in this GPU's copy of the file-scope `scratch`, jitter and outputs in the caller's device memory.
@@ -2125,7 +2222,17 @@ int rt_render_scene(int image_height, int image_width, int number_of_samples, co
     std::vector<uint8_t> rgb2[2] = {std::vector<uint8_t>(rgb_bytes), std::vector<uint8_t>(rgb_bytes)};
     std::future<void> writer;
     int wbuf = 0;
-    const bool pipeline = std::getenv("RT_NO_PIPELINE") == nullptr;  // (tuning knob)
+    bool pipeline = std::getenv("RT_NO_PIPELINE") == nullptr;  // (tuning knob)
+    {  // frames rendered band by band (render_frame) end with a wait and swap whole-frame buffers in: not pipelined
+        rt_render_params probe;
+        std::memset(&probe, 0, sizeof(probe));
+        probe.image_height = image_height;
+        probe.image_width = image_width;
+        probe.samples = number_of_samples;
+        probe.row_end = image_height;
+        probe.sampler = RT_SAMPLER_MT19937;
+        if (band_rows_for(&probe) != 0) pipeline = false;
+    }
     bool have_prev = false;
     int prev_t = 0, prev_cam = 0;
     top_up();
@@ -2182,7 +2289,7 @@ int rt_render_scene(int image_height, int image_width, int number_of_samples, co
         double t1 = now();
         // pipelined: this frame is enqueued behind the previous one; the previous frame is read back and
         // written while this one renders
-        if ((rc = render_impl(c, &p, pipeline))) return bail(rc);
+        if ((rc = render_frame(c, &p, pipeline))) return bail(rc);
         t_render += now() - t1;
         auto frame_path = [&](int tt, int cc) {
             // cpp/rtmain.cpp:58-60: rtimage_<timestep>_cam<camera>.ppm, zero-based
