@@ -216,6 +216,7 @@ typedef struct {
      * rt_last_stats gives the K launches' kernel time without a sync per step */
     double render_kernel_ms_total;
     uint64_t render_launches_timed;
+    uint64_t jitter_streams; /* MT19937 sampler: streams the launch's offsets were generated on (0: other samplers) */
 } rt_stats;
 int rt_last_stats(const rt_ctx *ctx, rt_stats *out);
 int rt_sync(rt_ctx *ctx);

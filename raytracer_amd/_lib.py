@@ -43,7 +43,8 @@ class Stats(C.Structure):
     _fields_ = [("render_kernel_ms", C.c_double), ("jitter_kernel_ms", C.c_double), ("host_jump_ms", C.c_double),
                 ("rays", C.c_uint64), ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64),
                 ("rays_hit", C.c_uint64), ("wave_node_fetches", C.c_uint64), ("wave_tri_fetches", C.c_uint64),
-                ("render_kernel_ms_total", C.c_double), ("render_launches_timed", C.c_uint64)]
+                ("render_kernel_ms_total", C.c_double), ("render_launches_timed", C.c_uint64),
+                ("jitter_streams", C.c_uint64)]
 
 
 # name -> (restype, argtypes).  Every symbol declared in include/rtgpu.h is listed here;

@@ -336,6 +336,12 @@ struct StreamPlan {
     uint64_t total_words = 0;  // rows*W*spp*4 (the last stream stops there)
 };
 
+// Frames from this many words on learn the stream count of their look-ahead fills (adapt_streams).
+uint64_t adapt_min_words() {
+    const char* e = std::getenv("RT_ADAPT_MIN_WORDS");  // (test knob: the suites' frames are far smaller)
+    return e ? (uint64_t)std::max(0.0, std::atof(e)) : (uint64_t(1) << 30);
+}
+
 StreamPlan plan_streams(int rows, int W, int spp, int frames = 1, int hidden_n = 0) {
     StreamPlan p;
     // One workgroup per stream.  Measured: a stream regenerates 624 words in ~1.2 us (a chain of dependent
@@ -355,7 +361,7 @@ StreamPlan plan_streams(int rows, int W, int spp, int frames = 1, int hidden_n =
     // ... and a look-ahead fill of such a frame, which nobody waits for, takes the number the context has learnt
     // (adapt_streams below): the sampler's workgroups hold wave slots the traversal kernel would use, so it should
     // run on as few as still finish well before the traversal it hides behind
-    if (hidden_n > 0 && (words >> 30) != 0) target = (uint64_t)hidden_n;
+    if (hidden_n > 0 && words >= adapt_min_words()) target = (uint64_t)hidden_n;
     if (const char* e = std::getenv("RT_JITTER_STREAMS")) target = (uint64_t)std::max(1, std::atoi(e));
     uint64_t stride = (words + target - 1) / target;
     stride = (stride + 623) / 624 * 624;
@@ -1302,7 +1308,7 @@ int launch_packet(rt_ctx* c, const rt_render_params* p, int tile_log2, int tiles
 void adapt_streams(rt_ctx* c, int rows, int W, int spp) {
     if (std::getenv("RT_NO_ADAPT_STREAMS") || std::getenv("RT_JITTER_STREAMS")) return;  // (tuning knobs)
     if (!c->kernel_ms_known || !c->jitter_timed || c->out_rows != rows || c->out_w != W || c->out_spp != spp) return;
-    if (((uint64_t(rows) * uint64_t(W) * uint64_t(spp) * 4u) >> 30) == 0) return;
+    if (uint64_t(rows) * uint64_t(W) * uint64_t(spp) * 4u < adapt_min_words()) return;
     const rt_ctx::JitterSlot& sl = c->slot[c->last_slot];  // the slot that launch read: its fill is complete
     if (sl.rows != rows || sl.W != W || sl.spp != spp || sl.frames != 1 || sl.states_n < 1) return;
     float sampler_ms = 0.f;
@@ -1312,7 +1318,9 @@ void adapt_streams(rt_ctx* c, int rows, int W, int spp) {
     }
     const double render_ms = c->stats.render_kernel_ms;
     if (!(sampler_ms > 0.f) || !(render_ms > 0.0)) return;
-    double want = double(sl.states_n) * double(sampler_ms) / (0.8 * render_ms);
+    const char* re = std::getenv("RT_ADAPT_RATIO");  // (test knob)
+    const double ratio = re ? std::max(1e-6, std::atof(re)) : 0.8;
+    double want = double(sl.states_n) * double(sampler_ms) / (ratio * render_ms);
     want = std::min(1024.0, std::max(256.0, std::ceil(want / 64.0) * 64.0));
     if (c->adapt_job.valid()) {
         if (c->adapt_job.wait_for(std::chrono::seconds(0)) != std::future_status::ready) return;
@@ -1488,6 +1496,7 @@ int render_impl(rt_ctx* c, const rt_render_params* p, bool pipelined) {
             }
             HIP_TRY(hipStreamWaitEvent(c->stream, c->slot[use].done, 0));
             c->jitter_timed = true;
+            c->stats.jitter_streams = (uint64_t)c->slot[use].states_n;
             c->pos += fw;
             if (slot_frame == c->slot[use].frames - 1) {
                 // the slot's last frame: its end state is the generator state at the new position

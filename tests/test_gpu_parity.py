@@ -659,3 +659,36 @@ def test_frame_groups_serve_consecutive_small_frames_and_the_state_catches_up(ct
     for f in range(10):
         assert np.array_equal(bits(plain[f]["intensity"]), bits(got[f]["intensity"])), f
     host.close()
+
+
+def test_learnt_sampler_stream_count_keeps_the_stream(ctx, monkeypatch):
+    """Look-ahead fills of very large frames change their number of sampler streams once the context has timed a
+    launch (rt_api.hip adapt_streams; new jump polynomials come from a helper thread).  The knobs make a small frame
+    count as very large and push the learnt count to its maximum: the frames of a loop must stay the oracle's over
+    one continuous stream, before, during and after the switch."""
+    import time
+    c, k = meshgen.plate(12)
+    host = ra.HostScene([c], [k], 0)
+    ctx.upload(host)
+    o = orc.Scene([c], [k], 0)
+    H, W, spp = 64, 96, 16
+    cam = meshgen.camera_arrays(W, H)
+    fw = H * W * spp * 4
+    monkeypatch.setenv("RT_ADAPT_MIN_WORDS", "0")
+    monkeypatch.setenv("RT_ADAPT_RATIO", "1e-5")
+    monkeypatch.setenv("RT_NO_FRAME_GROUPS", "1")  # (groups of frames per slot are not re-planned)
+    ctx.rng_seed(5489)
+    rng = orc.Rng()
+    streams = []
+    for f in range(14):
+        ctx.render(*cam, H, W, spp, hit_ids=True)
+        got = ctx.download()
+        streams.append(ctx.stats()["jitter_streams"])
+        want = o.render(*cam, H, W, spp, rng=rng)
+        mesh, elem = host.map_prims(got["hit_prim"])
+        assert np.array_equal(elem, want["hit_elem"]) and np.array_equal(bits(got["intensity"]), bits(want["intensity"])), f
+        assert ctx.rng_tell() == (f + 1) * fw
+        if f == 2:
+            time.sleep(0.5)  # the helper thread's polynomials are there by now
+    assert streams[0] >= 1 and max(streams) > streams[0], streams  # the count did change on the way
+    host.close()
