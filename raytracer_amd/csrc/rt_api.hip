@@ -489,13 +489,11 @@ int fill_slot(rt_ctx* c, int k, uint64_t ahead, int rows, int W, int spp, int fr
         hipLaunchKernelGGL(rtk::mt_jump_all_kernel, dim3(pl.n, rtk::JUMP_PARTS), dim3(rtk::JUMP_THREADS), kJumpLds,
                            c->rng_stream, ot.d_states.p, sl.d_states.p, poly);
         HIP_TRY(hipGetLastError());
-        if ((rc = dev_jump(c, sl.d_states.p, sl.d_end.p, pl.total_words))) return rc;
         hipLaunchKernelGGL(rtk::mt_jitter_kernel, dim3(pl.n), dim3(rtk::JITTER_THREADS), 0, c->rng_stream, sl.d_states.p, sl.buf.p,
                            (unsigned long long)(pl.stride / 2), (unsigned long long)(pl.total_words / 2));
         HIP_TRY(hipGetLastError());
     } else {
         if ((rc = dev_jump(c, c->d_state.p, sl.d_states.p, ahead + (c->pos - c->state_pos)))) return rc;
-        if ((rc = dev_jump(c, sl.d_states.p, sl.d_end.p, pl.total_words))) return rc;
         if ((rc = launch_jitter(c, sl.d_states.p, pl, sl.buf.p))) return rc;
     }
     sl.states_ok = true;
@@ -504,6 +502,9 @@ int fill_slot(rt_ctx* c, int k, uint64_t ahead, int rows, int W, int spp, int fr
     sl.states_n = pl.n;
     HIP_TRY(hipEventRecord(sl.t1, c->rng_stream));
     HIP_TRY(hipEventRecord(sl.done, c->rng_stream));
+    // the state at the slot's end is only needed when the slot's last frame has been handed out (a copy on this
+    // stream): its jump goes BEHIND the pairs, off the chain the traversal waits for
+    if ((rc = dev_jump(c, sl.d_states.p, sl.d_end.p, pl.total_words))) return rc;
     sl.host_ms = now_ms() - t0;
     sl.pos = c->pos + ahead;
     sl.rows = rows;

@@ -76,11 +76,25 @@ struct Centroid {
     double c[3];
 };
 
-// Elements (triangles of a mesh, or meshes of the scene) seen by the splitter.
+// Elements (triangles of a mesh, or meshes of the scene) seen by the splitter.  `rec` (BLAS builds): the elements'
+// boxes and centroids kept IN idx ORDER -- rec[i] belongs to element idx[i]; the partition pass permutes both --
+// so that the scans of a range read memory front to back instead of chasing idx into arrays in element order (the
+// values and the order they are combined in are the same: the tree does not change).  Null: indexed access.
+struct Rec {
+    Box box;
+    Centroid c;
+};
 struct Elements {
     const Centroid* cent;
     const Box* box;
+    Rec* rec = nullptr;
 };
+inline const Box& elem_box(const Elements& el, const int32_t* idx, int64_t i) {
+    return el.rec ? el.rec[i].box : el.box[idx[i]];
+}
+inline const double* elem_cent(const Elements& el, const int32_t* idx, int64_t i) {
+    return el.rec ? el.rec[i].c.c : el.cent[idx[i]].c;
+}
 
 // ---------------------------------------------------------------------------------------
 // Host parallelism.  A small persistent pool; parallel_for's caller takes part in its own job and
@@ -195,6 +209,7 @@ private:
     bool stop_ = false;
 };
 
+constexpr int64_t kTreeParMin = 1 << 13;  // trees over at least this many elements build their subtrees concurrently
 constexpr int64_t kParMin = 1 << 16;    // ranges at least this long are scanned by several threads
 constexpr int64_t kParChunk = 1 << 14;  // elements per chunk of such a scan
 
@@ -218,7 +233,7 @@ Box range_box(const Elements& el, const int32_t* idx, int64_t first, int64_t cou
     if (count < kParMin) {
         Box b;
         b.reset();
-        for (int64_t i = first; i < first + count; ++i) b.add_box(el.box[idx[i]]);
+        for (int64_t i = first; i < first + count; ++i) b.add_box(elem_box(el, idx, i));
         return b;
     }
     const int64_t max_chunks = (count + kParChunk - 1) / kParChunk;
@@ -227,7 +242,7 @@ Box range_box(const Elements& el, const int32_t* idx, int64_t first, int64_t cou
     for_chunks(first, count, nc, [&](int64_t c, int64_t lo, int64_t hi) {
         Box b;
         b.reset();
-        for (int64_t i = lo; i < hi; ++i) b.add_box(el.box[idx[i]]);
+        for (int64_t i = lo; i < hi; ++i) b.add_box(elem_box(el, idx, i));
         part[c] = b;
     });
     Box b;
@@ -245,7 +260,7 @@ bool choose_split(const Elements& el, const int32_t* idx, int64_t first, int64_t
     if (cb_known) {
         cb = *cb_known;  // centroid bounds of this range, accumulated while the parent was partitioned
     } else if (count < kParMin) {
-        for (int64_t i = first; i < first + count; ++i) cb.add_point(el.cent[idx[i]].c);
+        for (int64_t i = first; i < first + count; ++i) cb.add_point(elem_cent(el, idx, i));
     } else {
         const int64_t max_chunks = (count + kParChunk - 1) / kParChunk;
         std::vector<Box> part(static_cast<size_t>(max_chunks));
@@ -253,7 +268,7 @@ bool choose_split(const Elements& el, const int32_t* idx, int64_t first, int64_t
         for_chunks(first, count, nc, [&](int64_t c, int64_t lo, int64_t hi) {
             Box b;
             b.reset();
-            for (int64_t i = lo; i < hi; ++i) b.add_point(el.cent[idx[i]].c);
+            for (int64_t i = lo; i < hi; ++i) b.add_point(elem_cent(el, idx, i));
             part[c] = b;
         });
         for (int64_t c = 0; c < nc; ++c) cb.add_box(part[c]);
@@ -285,12 +300,11 @@ bool choose_split(const Elements& el, const int32_t* idx, int64_t first, int64_t
     const double cmin = cb.mn[axis];
     if (count < kParMin) {  // the common case: straight into the bins, nothing on the heap
         for (int64_t i = first; i < first + count; ++i) {
-            const int32_t e = idx[i];
-            double t = (el.cent[e].c[axis] - cmin) * inv_ext;
+            double t = (elem_cent(el, idx, i)[axis] - cmin) * inv_ext;
             int b = static_cast<int>(t * kBins);
             if (b == kBins) b = kBins - 1;
             bin_cnt[b]++;
-            bin_box[b].add_box(el.box[e]);
+            bin_box[b].add_box(elem_box(el, idx, i));
         }
     } else {
         struct Bins {
@@ -307,12 +321,11 @@ bool choose_split(const Elements& el, const int32_t* idx, int64_t first, int64_t
                 p.cnt[b] = 0;
             }
             for (int64_t i = lo; i < hi; ++i) {
-                const int32_t e = idx[i];
-                double t = (el.cent[e].c[axis] - cmin) * inv_ext;
+                double t = (elem_cent(el, idx, i)[axis] - cmin) * inv_ext;
                 int b = static_cast<int>(t * kBins);
                 if (b == kBins) b = kBins - 1;
                 p.cnt[b]++;
-                p.box[b].add_box(el.box[e]);
+                p.box[b].add_box(elem_box(el, idx, i));
             }
         });
         for (int64_t c = 0; c < nc; ++c)
@@ -395,17 +408,18 @@ int64_t partition(const Elements& el, int32_t* idx, int64_t first, int64_t count
         lc.reset();
         rc.reset();
         while (mid < end) {
-            const int32_t e = idx[mid];
-            const Centroid& c = el.cent[e];
-            if (c.c[axis] < pos) {
-                lb.add_box(el.box[e]);
-                lc.add_point(c.c);
+            const double* cc = elem_cent(el, idx, mid);
+            const Box& bx = elem_box(el, idx, mid);
+            if (cc[axis] < pos) {
+                lb.add_box(bx);
+                lc.add_point(cc);
                 ++mid;
             } else {
-                rb.add_box(el.box[e]);
-                rc.add_point(c.c);
+                rb.add_box(bx);
+                rc.add_point(cc);
                 --end;
                 std::swap(idx[mid], idx[end]);
+                if (el.rec) std::swap(el.rec[mid], el.rec[end]);
             }
         }
         sides->box[0] = lb;
@@ -418,11 +432,12 @@ int64_t partition(const Elements& el, int32_t* idx, int64_t first, int64_t count
         sides->cent_ok[1] = no_zero_component(rc);
     } else {
         while (mid < end) {
-            if (el.cent[idx[mid]].c[axis] < pos) {
+            if (elem_cent(el, idx, mid)[axis] < pos) {
                 ++mid;
             } else {
                 --end;
                 std::swap(idx[mid], idx[end]);
+                if (el.rec) std::swap(el.rec[mid], el.rec[end]);
             }
         }
     }
@@ -529,16 +544,92 @@ void build_tree(std::vector<HostNode>& nodes, const Elements& el, int32_t* idx, 
     root.count = n_elem;
     root.left = -1;
     root.first = 0;
-    if (n_elem < 2 * kParMin || Pool::get().width() == 1) {
+    // (from 8 K elements on: the multi-frame driver rebuilds meshes of a few 10 K triangles per timestep, and a
+    // build that only runs one thread per mesh leaves half of a 16-core host idle with 8 meshes)
+    if (n_elem < kTreeParMin || Pool::get().width() == 1) {
         nodes.reserve(static_cast<size_t>(n_elem) * 2 / std::max(1, max_leaf - 1) + 8);
         nodes.push_back(root);
         expand(nodes, el, idx, max_leaf, fallbacks, 0, nullptr);
         return;
     }
+    // The top of the tree: the splits of different nodes are independent of each other (disjoint ranges of idx),
+    // only the node NUMBERS depend on the order the reference's loop pops them in.  So the ranges are partitioned
+    // by recursive tasks (the two children of a node concurrently) into a pointer tree, and the loop is then
+    // replayed over that tree, serially and without touching an element, to hand out the numbers.
     std::vector<HostNode> top;
     top.push_back(root);
     std::vector<Deferred> deferred;
-    expand(top, el, idx, max_leaf, fallbacks, std::max<int64_t>(4096, n_elem / 64), &deferred);
+    const int64_t defer_below = std::max<int64_t>(n_elem >= 2 * kParMin ? 4096 : 256, n_elem / 64);
+    {
+        struct TopNode {
+            HostNode h{};
+            bool deferred = false;
+            std::unique_ptr<TopNode> l, r;
+        };
+        std::atomic<int64_t> fb{0};
+        std::function<void(TopNode*, bool, const Box&)> grow = [&](TopNode* t, bool cent_ok, const Box& cent) {
+            const int64_t count = t->h.count, first = t->h.first;
+            if (count <= max_leaf) return;
+            if (count <= defer_below) {
+                t->deferred = true;
+                return;
+            }
+            const Box parent = get_box(t->h);
+            Sides sides;
+            int64_t f = 0;
+            const int64_t nl = partition(el, idx, first, count, parent, cent_ok ? &cent : nullptr, f, &sides);
+            fb += f;
+            if (nl < 0) return;  // stays a leaf with `count` elements (possibly > max_leaf)
+            const int64_t nr = count - nl;
+            t->l.reset(new TopNode());
+            t->r.reset(new TopNode());
+            set_box(t->l->h, sides.box_ok[0] ? sides.box[0] : range_box(el, idx, first, nl));
+            t->l->h.count = nl;
+            t->l->h.left = -1;
+            t->l->h.first = static_cast<int32_t>(first);
+            set_box(t->r->h, sides.box_ok[1] ? sides.box[1] : range_box(el, idx, first + nl, nr));
+            t->r->h.count = nr;
+            t->r->h.left = -1;
+            t->r->h.first = static_cast<int32_t>(first + nl);
+            auto child = [&](int64_t k) {
+                if (k == 0)
+                    grow(t->l.get(), sides.cent_ok[0], sides.cent[0]);
+                else
+                    grow(t->r.get(), sides.cent_ok[1], sides.cent[1]);
+            };
+            if (std::min(nl, nr) > defer_below) {
+                Pool::get().parallel_for(2, child);
+            } else {
+                child(0);
+                child(1);
+            }
+        };
+        TopNode troot;
+        troot.h = root;
+        grow(&troot, false, Box{});
+        fallbacks += fb.load();
+        // replay of the reference's loop (see expand): pop, number the children, push right then left
+        std::vector<std::pair<const TopNode*, int32_t>> stack;
+        stack.push_back({&troot, 0});
+        while (!stack.empty()) {
+            const TopNode* t = stack.back().first;
+            const int32_t node = stack.back().second;
+            stack.pop_back();
+            if (t->h.count <= max_leaf) continue;
+            if (t->deferred) {
+                deferred.push_back({node, t->h.first, t->h.count, static_cast<int64_t>(top.size())});
+                continue;
+            }
+            if (!t->l) continue;
+            const int32_t left = static_cast<int32_t>(top.size());
+            top.push_back(t->l->h);
+            top.push_back(t->r->h);
+            top[node].left = left;
+            top[node].count = 0;
+            stack.push_back({t->r.get(), left + 1});
+            stack.push_back({t->l.get(), left});
+        }
+    }
 
     const int64_t nd = static_cast<int64_t>(deferred.size());
     std::vector<std::vector<HostNode>> sub(static_cast<size_t>(nd));
@@ -595,8 +686,7 @@ void build_tree(std::vector<HostNode>& nodes, const Elements& el, int32_t* idx, 
 }
 
 void build_one_blas(HostBlas& b, int32_t mesh, const double* coords_t, int64_t E, Centroid& mesh_cent) {
-    std::vector<Centroid> cent(static_cast<size_t>(E));
-    std::vector<Box> boxes(static_cast<size_t>(E));
+    std::vector<Rec> rec(static_cast<size_t>(E));  // boxes + centroids, permuted together with the index array
     Box mesh_box;
     mesh_box.reset();
     {
@@ -608,10 +698,10 @@ void build_one_blas(HostBlas& b, int32_t mesh, const double* coords_t, int64_t E
             mb.reset();
             for (int64_t e = lo; e < hi; ++e) {
                 const double* tc = coords_t + e * 9;
-                for (int i = 0; i < 3; ++i) cent[e].c[i] = (tc[i] + tc[i + 3] + tc[i + 6]) / 3.0;
-                boxes[e].reset();
-                for (int v = 0; v < 3; ++v) boxes[e].add_point(tc + 3 * v);
-                mb.add_box(boxes[e]);
+                for (int i = 0; i < 3; ++i) rec[e].c.c[i] = (tc[i] + tc[i + 3] + tc[i + 6]) / 3.0;
+                rec[e].box.reset();
+                for (int v = 0; v < 3; ++v) rec[e].box.add_point(tc + 3 * v);
+                mb.add_box(rec[e].box);
             }
             part[c] = mb;
         });
@@ -623,7 +713,7 @@ void build_one_blas(HostBlas& b, int32_t mesh, const double* coords_t, int64_t E
     b.mesh = mesh;
     b.sorted_to_elem.resize(static_cast<size_t>(E));
     for (int64_t e = 0; e < E; ++e) b.sorted_to_elem[e] = static_cast<int32_t>(e);
-    Elements el{cent.data(), boxes.data()};
+    Elements el{nullptr, nullptr, rec.data()};
     build_tree(b.nodes, el, b.sorted_to_elem.data(), E, 4, b.midpoint_fallbacks);
 }
 
