@@ -458,6 +458,7 @@ def main():
         lane_ops = None
         step_ops = None
         step_kernels = None
+        scalar_instr = None
         pmc_note = None
         pmc_path = os.path.join(ROOT, "profiles", f"pmc_{args.workload}.json")
         if os.path.exists(pmc_path):
@@ -473,6 +474,9 @@ def main():
                     traffic = pmc.get("hbm_bytes_per_launch")
                     vi = pmc.get(pmc.get("dominant_kernel", ""), {}).get("SQ_INSTS_VALU")
                     lane_ops = vi * 64 if vi else None
+                    dom = pmc.get(pmc.get("dominant_kernel", ""), {})
+                    if all(k in dom for k in ("SQ_INSTS_SALU", "SQ_INSTS_BRANCH", "SQ_INSTS_SMEM")):
+                        scalar_instr = dom["SQ_INSTS_SALU"] + dom["SQ_INSTS_BRANCH"] + dom["SQ_INSTS_SMEM"]
                     # every kernel of a steady-state step (they share the GPU with each other): launches per step x
                     # SQ_INSTS_VALU per launch
                     per_step = {"render_packet_kernel": 1, "mt_jitter_kernel": 1, "mt_jump_all_kernel": 1,
@@ -505,6 +509,14 @@ def main():
                     "kernel_alone": {"kernel_ms": alone_ms,
                                      "achieved": lane_ops / (alone_ms * 1e-3) / 1e12 if lane_ops and alone_ms else None,
                                      "frac": lane_ops / (alone_ms * 1e-3) / FP64_LANE_OPS_PEAK if lane_ops and alone_ms else None},
+                    # the other issue port: SALU + branch + SMEM instructions of the kernel against one instruction per
+                    # SIMD per 4 cycles (1024 SIMDs x 2.4 GHz / 4)
+                    "scalar_issue": {"instructions_per_launch": scalar_instr, "peak_ginstr_s": 1024 * 2.4 / 4,
+                                     "frac_alone": scalar_instr / (alone_ms * 1e-3) / (1024 * 2.4e9 / 4)
+                                     if scalar_instr and alone_ms else None,
+                                     "frac": scalar_instr / (kms * 1e-3) / (1024 * 2.4e9 / 4) if scalar_instr else None,
+                                     "note": "per batch the kernel issues about as many scalar-side as vector instructions; "
+                                             "both ports take one instruction per SIMD every 4 cycles"},
                     "gpu_step": {"lane_ops_per_step": step_ops, "by_kernel": step_kernels,
                                  "ms_per_step": elapsed / args.steps * 1e3,
                                  "achieved": step_ops / (elapsed / args.steps) / 1e12 if step_ops else None,
