@@ -362,7 +362,7 @@ __global__ __launch_bounds__(NT) void render_kernel(const RenderArgs a) {
         if (px < a.W && py < a.rows) {
             // cpp/rtrender.cpp:61-65
             const double gray = (0.2126 * s_acc[0][tid] + 0.7152 * s_acc[1][tid]) + 0.0722 * s_acc[2][tid];
-            const double inten = gray / (double)spp;
+            const double inten = gray / (double)a.spp;
             const int gb = (int)(inten * 255.99);
             const size_t pidx = (size_t)py * a.W + px;
             a.intensity[pidx] = inten;
@@ -1431,8 +1431,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 8), amdgp
         const int m = wave_pixel(ml, wv, m0, a.interleave);
         q.px = tx0 + (int)compact1by1((uint32_t)m);
         q.py = ty0 + (int)compact1by1((uint32_t)m >> 1);
-        q.active = (rr < n_rays) && (q.px < a.W) && (q.py < a.rows);
-        q.sidx = q.active ? ((size_t)q.py * a.W + q.px) * (size_t)spp + k : 0;
+        // P64 with 32 < a.spp < 64 (host: pair64 = 1): one pixel per batch all the same, lanes a.spp.. idle -- their
+        // colours stay 0.0, which the in-order sums below add at the end without changing a bit (the sums start at
+        // +0.0, so they are never -0.0)
+        q.active = (rr < n_rays) && (q.px < a.W) && (q.py < a.rows) && (!P64 || k < a.spp);
+        q.sidx = q.active ? ((size_t)q.py * a.W + q.px) * (size_t)(P64 ? a.spp : spp) + k : 0;
         q.jit = d2{0.0, 0.0};
         // streamed once: non-temporal, so the 16 B/sample stream does not displace tree nodes in L2
         if (q.active)
@@ -1673,7 +1676,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 8), amdgp
         if (px < a.W && py < a.rows) {
             // cpp/rtrender.cpp:61-65
             const double gray = (0.2126 * wacc[0][lane] + 0.7152 * wacc[1][lane]) + 0.0722 * wacc[2][lane];
-            const double inten = gray / (double)spp;
+            const double inten = gray / (double)a.spp;
             const int gb = (int)(inten * 255.99);
             const size_t pidx = (size_t)py * a.W + px;
             karg_ptr<double, offsetof(PacketArgs, intensity)>()[pidx] = inten;
