@@ -1273,13 +1273,23 @@ int launch_packet_kernel(rt_ctx* c, const rt_render_params* p, int tile_log2, in
         c->stack_need <= rtk::PAIR64_STACK &&
         !std::getenv("RT_NO_PAIR64"))
         for (int q = spp >> 6; q; q >>= 1) ++a.pair64;
-    // 49..63 samples: one pixel per batch with the last lanes idle beats batches that straddle pixels (their cuts are
-    // those of bigger blocks, and their index arithmetic is per lane): 2048^2, 1 M triangles, 50 spp 5.85 -> 5.21 ms,
-    // 56 spp 5.99 -> 5.29, 63 spp 7.01 -> 5.40; 48 spp 5.08 -> 5.17 and 40 spp 4.57 -> 5.05 stay generic
-    static const int pad_from = std::getenv("RT_PAD64_FROM") ? std::atoi(std::getenv("RT_PAD64_FROM")) : 49;  // (tuning knob)
-    if (a.pair64 == 0 && spp >= pad_from && spp < 64 && (tile_log2 == 3 || tile_log2 == 2) &&
-        c->stack_need <= rtk::PAIR64_STACK && !std::getenv("RT_NO_PAIR64"))
-        a.pair64 = 1;
+    // Sample counts a little below 64 * 2^n (from 49/64 of it): the same instantiation with the last lanes idle beats
+    // batches that straddle pixels (their cuts are those of bigger blocks, and their index arithmetic is per lane):
+    // 2048^2, 1 M triangles, 50 spp 5.85 -> 5.21 ms, 56 spp 5.99 -> 5.29, 63 spp 7.01 -> 5.40; 48 spp 5.08 -> 5.17 and
+    // 40 spp 4.57 -> 5.05 stay generic
+    static const int pad_from = std::getenv("RT_PAD64_FROM") ? std::atoi(std::getenv("RT_PAD64_FROM")) : 49;  // (tuning knob, per 64)
+    if (a.pair64 == 0 && spp > 32 && c->stack_need <= rtk::PAIR64_STACK && !std::getenv("RT_NO_PAIR64")) {
+        int padded = 64, lg = 0;
+        while (padded < spp) {
+            padded <<= 1;
+            ++lg;
+        }
+        // (two or more batches per pixel: the idle lanes are all in the last one; 100 of 128 lost 2 %, 120 won 9 %)
+        const int from = lg == 0 ? pad_from : std::max(pad_from, 56);
+        if (spp != padded && int64_t(spp) * 64 >= int64_t(padded) * from &&
+            (tile_log2 == 3 || tile_log2 == 2 || (tile_log2 == 1 && padded >= 128)))
+            a.pair64 = 1 + lg;
+    }
     a.interleave = std::getenv("RT_NO_INTERLEAVE") ? 0 : (a.pair64 ? 1 : 0);
     if (const char* e = std::getenv("RT_INTERLEAVE")) a.interleave = std::atoi(e);  // experiment: 0, 1, 2, 4, ...
     if (a.interleave && ((a.interleave & (a.interleave - 1)) || a.interleave > ((1 << (2 * tile_log2)) >> 2))) a.interleave = 0;
