@@ -576,7 +576,12 @@ int stage_scene(rt_ctx* c, const rt::Scene& s) {
     // these buffers may have been the current set until recently: wait for the last render that read them
     if (st->used && hipEventSynchronize(st->last_use) != hipSuccess) return give_up();
     st->used = false;
+    const double t_copy0 = now_ms();
     if (copy_scene_to(st->b, s, st->stream) != RT_OK) return give_up();
+    if (std::getenv("RT_BUILD_TIMING"))
+        std::fprintf(stderr, "stage_scene: %.1f MB copied to the device in %.2f ms\n",
+                     (s.dev_nodes.size() * sizeof(rt::DevNode) + s.tris.size() * 8 + s.colors.size() * 8) / 1e6,
+                     now_ms() - t_copy0);
     st->n_nodes = s.dev_nodes.size();
     st->n_tlas = s.dev_tlas.size();
     st->n_tris = (int64_t)s.prim_mesh.size();

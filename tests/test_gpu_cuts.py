@@ -151,3 +151,40 @@ def test_small_frames_get_no_cuts_by_default(ctx, monkeypatch):
     ctx.render(*cam, 48, 64, 64)
     assert ctx.last_cuts()[0].shape[0] == 24 * 32
     host.close()
+
+
+def test_triangle_edges_on_block_corners_and_samples_on_edges(ctx, monkeypatch):
+    """Adversarial for the trimmed leaves (cut_trim): a flat plate whose quad edges project EXACTLY onto pixel
+    corners (every second one, so also onto the corners of the 2 x 2 blocks), a camera whose pixel grid is made of
+    binary fractions, and explicit sample offsets from {-0.5, 0, +0.5} (rays through edges and vertices) and within
+    2^-30 of them.  The block-level test must keep every triangle such a ray can hit: cut walk == root walk."""
+    H, W, spp = 32, 48, 64
+    d = 2.0 ** -5
+    cam_c = np.zeros(3)
+    p00 = np.array([-(W - 1) / 2 * d, (H - 1) / 2 * d, -1.0])
+    spacing = np.array([[d, 0.0, 0.0], [0.0, -d, 0.0]])
+    # plate at z = -2: a vertex at 2 * (pixel corner) projects onto that corner; quads of 2 x 2 pixels
+    z = -2.0
+    xs = 2.0 * (p00[0] + (np.arange(0, W + 1, 2) - 0.5) * d)
+    ys = 2.0 * (p00[1] - (np.arange(0, H + 1, 2) - 0.5) * d)
+    tris = []
+    for i in range(len(xs) - 1):
+        for j in range(len(ys) - 1):
+            a, b = (xs[i], ys[j + 1], z), (xs[i + 1], ys[j + 1], z)
+            c, e = (xs[i + 1], ys[j], z), (xs[i], ys[j], z)
+            tris += [(a, b, c), (a, c, e)]  # counter-clockwise seen from the camera (+z side)
+    coords = np.array(tris, np.float64)[None]
+    colors = np.linspace(0.1, 0.9, coords.shape[1])[None, :, None].repeat(3, axis=2)
+    host = ra.HostScene([coords], [colors], 0)
+    ctx.upload(host)
+    rng = np.random.default_rng(17)
+    n = H * W * spp
+    base = rng.choice([-0.5, 0.0, 0.5], size=(n, 2))
+    nudge = rng.choice([0.0, 2.0 ** -30, -(2.0 ** -30), 2.0 ** -52], size=(n, 2))
+    jit = np.clip(base + nudge, -0.5, 0.5)
+    a = both_ways(ctx, monkeypatch, (cam_c, p00, spacing), H, W, spp, jitter=jit)
+    assert (a["hit_prim"] >= 0).mean() > 0.9
+    # and with the sampler's own offsets
+    both_ways(ctx, monkeypatch, (cam_c, p00, spacing), H, W, spp)
+    both_ways(ctx, monkeypatch, (cam_c, p00, spacing), H, W, 50)
+    host.close()
