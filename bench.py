@@ -256,8 +256,8 @@ def rehearse(rank, world, local_rank):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--workload", default=os.environ.get("RT_BENCH_WORKLOAD", "c4"))
     ap.add_argument("--cpu-rays", type=float, default=40e6, help="rays in the CPU-baseline sample, about 10 s of one core (0 = skip)")
     ap.add_argument("--no-hit-ids", action="store_true")
