@@ -44,7 +44,11 @@ def kernel_source_hash():
     h = hashlib.sha256()
     for rel in ("raytracer_amd/csrc/rt_kernels.hip.hpp", "raytracer_amd/csrc/rt_kernels_fp32.hip.hpp",
                 "raytracer_amd/csrc/rt_bvh.hpp", "raytracer_amd/csrc/Makefile"):
-        h.update(open(os.path.join(ROOT, rel), "rb").read())
+        for line in open(os.path.join(ROOT, rel), "rb").read().splitlines():
+            # whole-line comments and blank lines do not reach the instruction stream
+            t = line.strip()
+            if t and not t.startswith(b"//") and not t.startswith(b"#  ") and not (rel.endswith("Makefile") and t.startswith(b"#")):
+                h.update(t + b"\n")
     return h.hexdigest()[:16]
 
 

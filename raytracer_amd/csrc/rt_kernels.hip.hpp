@@ -6,7 +6,10 @@
 //   render_packet_kernel   THE hot kernel: ray generation + wave-packet TLAS/BLAS traversal on the scalar
 //                      unit + Moller-Trumbore + shading + in-order sample accumulation + luma/quantise
 //                      (reference: cpp/rtrender.cpp:13-67, cpp/rtrayintersection.cpp:36-228);
-//                      <COUNT, P64>: with visit counters / the 64-spp instantiation (a batch = one pixel)
+//                      <COUNT, P64>: with visit counters / the one-pixel-per-batch instantiation (64 * 2^n spp
+//                      and a little below)
+//   cut_level_kernel   per pixel block and quadtree level: the cut at which the block's rays start their walk
+//                      (conservative block-level classification of boxes and triangles; same hits, bit for bit)
 //   render_kernel      the same per lane (LDS or global stack): trees deeper than the packet stack
 //   trace_kernel       the same traversal for caller-supplied rays (rt_trace_rays, test seam)
 //   mt_jump_kernel / mt_jump_tree_kernel / mt_jump_all_kernel   GF(2) jump-ahead of MT19937 states
