@@ -1,6 +1,6 @@
 """Soak test of rt_render_scene at scale: the same job (8 meshes rebuilt per timestep, 2 cameras, 64 spp, large
-frames) through the pipelined driver and with RT_NO_PIPELINE=1 / RT_BUILD_AHEAD=1 in a child process; every P6
-file must be byte-identical.  Usage: python profiles/tools/soak_driver.py [T] [size]"""
+frames) through the pipelined driver (cuts, prep + cut kernels beside the previous frame) and with RT_NO_PIPELINE=1 /
+RT_BUILD_AHEAD=1 / RT_NO_CUT=1 / RT_NO_PREP_OVERLAP=1 in a child process; every P6 file must be byte-identical.  Usage: python profiles/tools/soak_driver.py [T] [size]"""
 import ctypes as C
 import hashlib
 import os
@@ -60,7 +60,8 @@ if __name__ == "__main__":
     b = tempfile.mkdtemp(prefix="rtsoak_b_")
     el = run(T, size, a)
     print(f"pipelined: {2 * T} frames of {size}x{size}x64 in {el:.2f} s ({2 * T / el:.1f} frames/s)", flush=True)
-    env = dict(os.environ, RT_NO_PIPELINE="1", RT_BUILD_AHEAD="1")
+    # the child: no pipelining, one build at a time, the walk from the root (no cuts), prep on the traversal stream
+    env = dict(os.environ, RT_NO_PIPELINE="1", RT_BUILD_AHEAD="1", RT_NO_CUT="1", RT_NO_PREP_OVERLAP="1")
     subprocess.run([sys.executable, __file__, str(T), str(size), "child", b], check=True, env=env)
     da, db = digest(a), digest(b)
     assert len(da) == 2 * T, len(da)
@@ -72,4 +73,4 @@ if __name__ == "__main__":
     if bad:
         print("DIFFERENT:", bad)
         sys.exit(1)
-    print(f"all {len(da)} files identical to the unpipelined run", flush=True)
+    print(f"all {len(da)} files identical to the unpipelined root-walk run", flush=True)
