@@ -593,6 +593,9 @@ struct WaveCounters {
     unsigned long long tri_steps;    // triangle records fetched by the wave
 };
 
+#ifndef RT_P64_VECTOR_CUT
+#define RT_P64_VECTOR_CUT 1
+#endif
 constexpr uint32_t CUT_NODE_ENTRY = rt::DESC_TLAS | rt::DESC_ROOT;  // cut entry: BLAS node tested per ray (see "Tile cuts")
 // A CUT_NODE_ENTRY with this bit names a LEAF whose triangle range is overridden by the NEXT word of the list (a leaf
 // descriptor of a sub-range: cut_trim).  Cuts are only made for the packet kernels, whose node indices are < 2^26.
@@ -1444,7 +1447,23 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 8), amdgp
         if (q.active)
             q.jit = __builtin_nontemporal_load(karg_ptr<const d2, offsetof(PacketArgs, jitter)>() + q.sidx);
         q.vcut = 0u;
-        if (a.cut_lo >= 0) {
+        if (P64 && RT_P64_VECTOR_CUT && a.cut_lo >= 0) {
+            // one pixel per batch: the cut is the finest level's, always; its address is per-lane arithmetic on the
+            // (uniform) pixel coordinates that already sit in VGPRs -- the scalar unit only fetches the level's table
+            unsigned long long base_ptr;
+            uint32_t ctx;
+            const auto kseg = __builtin_amdgcn_kernarg_segment_ptr();
+            const uint32_t o1 = (uint32_t)offsetof(PacketArgs, cut_lvl) + 8u * (uint32_t)a.cut_lo;
+            const uint32_t o2 = (uint32_t)offsetof(PacketArgs, cut_tx) + 4u * (uint32_t)a.cut_lo;
+            asm volatile("s_load_dwordx2 %0, %2, %3\n\ts_load_dword %1, %2, %4\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&s"(base_ptr), "=&s"(ctx)
+                         : "s"(kseg), "s"(o1), "s"(o2)
+                         : "memory");
+            // (cut_eff[cut_lo] == cut_lo: the finest level is always made)
+            const uint32_t blk = (uint32_t)(q.py >> a.cut_lo) * ctx + (uint32_t)(q.px >> a.cut_lo);
+            const uint32_t* const cp = reinterpret_cast<const uint32_t*>(base_ptr) + (size_t)blk * CUT_WORDS;
+            if (lane < CUT_WORDS && q.px < a.W && q.py < a.rows) q.vcut = cp[lane];
+        } else if (a.cut_lo >= 0) {
             const int last = min(63, n_rays - 1 - base);
             const int mf = __builtin_amdgcn_readfirstlane(m), ml2 = P64 ? mf : __builtin_amdgcn_readlane(m, last);
             const int pxf = __builtin_amdgcn_readfirstlane(q.px), pyf = __builtin_amdgcn_readfirstlane(q.py);
