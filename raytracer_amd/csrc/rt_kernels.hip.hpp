@@ -593,6 +593,9 @@ struct WaveCounters {
     unsigned long long tri_steps;    // triangle records fetched by the wave
 };
 
+#ifndef RT_QUICK_DISPATCH
+#define RT_QUICK_DISPATCH 1
+#endif
 #ifndef RT_P64_VECTOR_CUT
 #define RT_P64_VECTOR_CUT 1
 #endif
@@ -1326,6 +1329,9 @@ __device__ __forceinline__ int batch_cut_entries(const uint32_t vcut, const unsi
 }
 
 // ---- the compiler's fp64 division, for operands that need no scaling (see render_packet_kernel) ----
+__device__ __forceinline__ uint32_t hi_word(const double x) {
+    return (uint32_t)(__builtin_bit_cast(unsigned long long, x) >> 32);
+}
 __device__ __forceinline__ uint32_t hi_abs(const double x) {
     return (uint32_t)(__builtin_bit_cast(unsigned long long, x) >> 32) & 0x7fffffffu;
 }
@@ -1562,17 +1568,41 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 8), amdgp
         const unsigned long long amask = __builtin_amdgcn_ballot_w64(active);
         if (amask != 0ull) {
             WaveCounters wc = {0ull, 0ull, 0ull, 0ull};
-            // per axis: do all active lanes look the same way?  (inactive lanes are masked out of every result)
-            const unsigned long long ngx = __builtin_amdgcn_ballot_w64(ix < 0.0) & amask;
-            const unsigned long long ngy = __builtin_amdgcn_ballot_w64(iy < 0.0) & amask;
-            const unsigned long long ngz = __builtin_amdgcn_ballot_w64(iz < 0.0) & amask;
-            const bool uni = (ngx == 0ull || ngx == amask) && (ngy == 0ull || ngy == amask) &&
-                             (ngz == 0ull || ngz == amask) && a.fast_ok == 2;
-            const int n_ent = batch_cut_entries(cs.vcut, amask, ngx, ngy, ngz, cs.jit.x, cs.jit.y);
-            if (__builtin_amdgcn_ballot_w64(risky) != 0ull) {
+            // The common case first, decided with ONE ballot: the batch's cut is valid and promises a sign for every
+            // axis (no "mixed" axis) -- then the octant is the header's, and all that is left to check per lane is that
+            // the ray is one the cut was made for: tame, offsets within +-0.5, signs as promised (the sign bit is the
+            // sign: a tame 1/d is neither a zero nor a NaN).  Per-lane flags and a vector compare instead of three
+            // ballots and a dozen scalar compares: the kernel is bound by scalar issue.
+            bool quick = false;
+            int oct = 0, n_ent = -1;
+            bool uni = false;
+            const uint32_t hdr0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)cs.vcut);
+            if (RT_QUICK_DISPATCH && (hdr0 & CUT_VALID) && ((hdr0 >> 8) & 0x2au) == 0u && a.fast_ok == 2) {
+                const uint32_t want = ((hdr0 >> 8) & 1u) | ((hdr0 >> 9) & 2u) | ((hdr0 >> 10) & 4u);  // kind 1 = negative
+                const uint32_t sb = (hi_word(ix) >> 31) | ((hi_word(iy) >> 31) << 1) | ((hi_word(iz) >> 31) << 2);
+                const bool fits = tame && sb == want && __builtin_fabs(cs.jit.x) <= 0.5 && __builtin_fabs(cs.jit.y) <= 0.5;
+                if ((__builtin_amdgcn_ballot_w64(!fits) & amask) == 0ull) {
+                    quick = true;
+                    uni = true;
+                    oct = (int)want;
+                    n_ent = (int)(hdr0 & 0xffu);
+                }
+            }
+            bool any_risky = false;
+            if (!quick) {
+                // per axis: do all active lanes look the same way?  (inactive lanes are masked out of every result)
+                const unsigned long long ngx = __builtin_amdgcn_ballot_w64(ix < 0.0) & amask;
+                const unsigned long long ngy = __builtin_amdgcn_ballot_w64(iy < 0.0) & amask;
+                const unsigned long long ngz = __builtin_amdgcn_ballot_w64(iz < 0.0) & amask;
+                uni = (ngx == 0ull || ngx == amask) && (ngy == 0ull || ngy == amask) && (ngz == 0ull || ngz == amask) &&
+                      a.fast_ok == 2;
+                n_ent = batch_cut_entries(cs.vcut, amask, ngx, ngy, ngz, cs.jit.x, cs.jit.y);
+                oct = (ngx != 0ull ? 1 : 0) | (ngy != 0ull ? 2 : 0) | (ngz != 0ull ? 4 : 0);
+                any_risky = __builtin_amdgcn_ballot_w64(risky) != 0ull;
+            }
+            if (any_risky) {
                 trace_packet<false, -1, COUNT>(a.sc, amask, dx, dy, dz, ix, iy, iz, wstk, h, wc, 0u, -1);
             } else if (uni) {
-                const int oct = (ngx != 0ull ? 1 : 0) | (ngy != 0ull ? 2 : 0) | (ngz != 0ull ? 4 : 0);
                 switch (oct) {
 #define RT_OCT_CASE(O)                                                                                       \
     case O:                                                                                                  \
