@@ -1399,8 +1399,10 @@ int render_impl(rt_ctx* c, const rt_render_params* p, bool pipelined) {
     pipelined = pipelined && p->sampler == RT_SAMPLER_MT19937 && p->flags == 0;
     int rc;
     // ---- traversal launch shape ----
-    // the packet kernels address nodes with a 32-bit scalar byte offset: node array < 4 GB (6.7e7 nodes)
-    const bool packet = c->stack_need <= rtk::PACKET_STACK && !force_per_lane() && c->n_nodes < (size_t(1) << 26);
+    // the packet kernels address nodes and triangle records with 32-bit scalar byte offsets: both arrays < 4 GB
+    // (6.7e7 nodes of 64 bytes, 3.3e7 triangles of 128)
+    const bool packet = c->stack_need <= rtk::PACKET_STACK && !force_per_lane() && c->n_nodes < (size_t(1) << 26) &&
+                        c->n_tris < (int64_t(1) << 25);
     const int tile_log2 = pick_tile_log2(packet || (p->flags & RT_FLAG_FP32), spp, W, rows);
     const int ts = 1 << tile_log2;
     const int tiles_x = (W + ts - 1) / ts;
@@ -1850,7 +1852,7 @@ int rt_render_static(rt_ctx* c, const rt_render_params* p, const double* d_jitte
     if ((p->flags & RT_FLAG_HIT_IDS) && !d_hit_prim)
         return fail(RT_E_INVALID, "rt_render_static: RT_FLAG_HIT_IDS needs a hit-id device pointer");
     if ((int64_t)spp * 256 > (int64_t)1 << 30) return fail(RT_E_LIMIT, "rt_render_static: samples per pixel too large");
-    if (c->stack_need > rtk::PACKET_STACK || c->n_nodes >= (size_t(1) << 26))
+    if (c->stack_need > rtk::PACKET_STACK || c->n_nodes >= (size_t(1) << 26) || c->n_tris >= (int64_t(1) << 25))
         return fail(RT_E_LIMIT, "rt_render_static: the tree needs the per-lane kernel (traversal stack > 128 entries)");
     // partition of the scratch array: [counters 256 B][cam_tlas][cam_nodes][cam_tris], each 256-byte aligned
     auto up256 = [](size_t v) { return (v + 255) & ~size_t(255); };

@@ -605,6 +605,83 @@ constexpr uint32_t CUT_NODE_ENTRY = rt::DESC_TLAS | rt::DESC_ROOT;  // cut entry
 constexpr uint32_t CUT_TRIM = 0x10000000u;
 constexpr uint32_t CUT_NODE_IDX = 0x03FFFFFFu;
 
+// The triangles of a leaf descriptor (a count field of 8 names a range in leaf_ext) against the lanes of `inm`, in order, with the strict `<` on t of the reference (rtrayintersection.cpp:79-106).
+// The records are addressed with a 32-bit scalar byte offset (the host sends scenes of >= 2^25 triangles to the
+// per-lane kernel): one add and one compare per triangle on the scalar unit, which is this kernel's busiest.
+template <bool FAST, bool COUNT>
+__device__ __forceinline__ void test_leaf(const PacketScene& sc, const uint32_t leaf, const unsigned long long inm,
+                                          const double dx, const double dy, const double dz, Hit& h, WaveCounters& wc) {
+    uint32_t first = leaf & rt::DESC_TRI_MASK;
+    uint32_t cnt = ((leaf >> 28) & 7u) + 1u;
+    if (cnt == 8u) {
+        cuptr ext = (cuptr)(const void*)sc.leaf_ext;
+        const uint32_t e = first;
+        first = ext[2 * e];
+        cnt = ext[2 * e + 1];
+    }
+    if (COUNT) {
+        wc.tris += (unsigned long long)cnt * (unsigned)__builtin_popcountll(inm);
+        wc.tri_steps += cnt;
+    }
+    const bool in = __builtin_amdgcn_inverse_ballot_w64(inm);
+    uint32_t off = first << 7;  // sizeof(CamTri) == 128
+    const uint32_t end = off + (cnt << 7);
+    do {
+        // the whole 128-byte record in one round trip (both 64-byte lines requested together): staged
+        // loads (edges, then tv/q, then tnum) put up to three dependent scalar-cache misses on the
+        // wave's critical path per triangle
+        u32x16 ta, tb;
+        asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx16 %1, %2, %3 offset:0x40\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(ta), "=&s"(tb)
+                     : "s"(sc.tris), "s"(off)
+                     : "memory");
+        const double e0x = sgpr_f64(ta, 0), e0y = sgpr_f64(ta, 1), e0z = sgpr_f64(ta, 2);
+        const double e2x = sgpr_f64(ta, 3), e2y = sgpr_f64(ta, 4), e2z = sgpr_f64(ta, 5);
+        const double tvx = sgpr_f64(ta, 6), tvy = sgpr_f64(ta, 7), tvz = sgpr_f64(tb, 0);
+        const double qx = sgpr_f64(tb, 1), qy = sgpr_f64(tb, 2), qz = sgpr_f64(tb, 3);
+        const double tnum = sgpr_f64(tb, 4);
+        // rtrayintersection.cpp:79-106, with the ray-independent parts precomputed
+        const double px = dy * e2z - dz * e2y;
+        const double py = dz * e2x - dx * e2z;
+        const double pz = dx * e2y - dy * e2x;
+        const double det = (e0x * px + e0y * py) + e0z * pz;
+        bool need = in && det > 1e-6;
+        double unum = 0.0, vnum = 0.0;
+        if (need) {
+            unum = (tvx * px + tvy * py) + tvz * pz;
+            vnum = (dx * qx + dy * qy) + dz * qz;
+            // Sure rejects, decided on the numerators so that a triangle none of the wave's rays can
+            // hit costs no division: with 1e-6 < det < 2^700 (FAST: every |coordinate - camera| <
+            // 1e100 and |direction| <= 1 bound det by 2.4e201) the rounded 1/det is a normal number
+            // >= 2^-700 with relative error 2^-53, so
+            //   num < -2^-300        =>  num * inv is a normal negative number: `>= 0` fails;
+            //   unum + vnum > det * (1 + 2^-30)  =>  had both u in [0,1] and v >= 0 held, u + v would
+            //                            exceed 1 by 2^-31, far beyond the four roundings involved.
+            // NaNs compare false and take the full path.  Lanes that are not sure rejects compute
+            // exactly what they did before, so results are unchanged.
+            if (FAST) {
+                const double lo = __builtin_fmin(unum, vnum);
+                need = !(lo < -0x1p-300 || (unum + vnum) > det * (1.0 + 0x1p-30));
+            }
+        }
+        if (need) {
+            const double inv = 1.0 / det;
+            const double u = unum * inv;
+            const double v = vnum * inv;
+            const double t = tnum * inv;
+            const bool ok = (u >= 0.0) && (u <= 1.0) && (v >= 0.0) && ((u + v) <= 1.0) && (t >= 0.0) &&
+                            (t <= __builtin_inf());
+            if (ok && t < h.t) {
+                h.t = t;
+                h.u = u;
+                h.v = v;
+                h.prim = (int32_t)(off >> 7);
+            }
+        }
+        off += 128u;
+    } while (off != end);
+}
+
 // Entry list (tile cut, see cut_level_kernel): n_entries < 0 -- walk from the TLAS root (the reference's own walk);
 // otherwise lane 1 + i of `vlist` holds entry i, a descriptor at which the walk (re)starts with every valid lane
 // taking part, in the reference's visit order.  The nodes above the entries are not tested: the cut guarantees
@@ -616,19 +693,89 @@ __device__ __forceinline__ void trace_packet(const PacketScene& sc, const unsign
                                           const uint32_t vlist, int n_entries) {
     int sp = 0;
     int ei = 1;
-    uint32_t cur = rt::DESC_TLAS;
     if (n_entries < 0) {
+        // the reference's own walk: the TLAS root is the one thing pending
         n_entries = 0;
-    } else {
-        if (n_entries == 0) return;
-        cur = (uint32_t)__builtin_amdgcn_readlane((int)vlist, 1);
+        wstk[sp++] = make_uint4(rt::DESC_TLAS, (uint32_t)valid_mask, (uint32_t)(valid_mask >> 32), 0u);
     }
-    unsigned long long inm = valid_mask;
+    // One round per pending item (stack first, else the next entry of the cut), written as a forward-only body with
+    // a single back edge and ONE call site of the triangle test: loops with several exits make the compiler carry
+    // guard variables, two call sites two copies of the hit -- on the scalar unit, this kernel's busiest.  A trimmed
+    // leaf, most of a fine cut, costs ~25 scalar instructions this way (it was ~75).
     for (;;) {
-        // ---- descend through internal BLAS nodes (the hot loop) ----
+        uint32_t cur;
+        unsigned long long inm = valid_mask;  // an entry: every valid lane takes part again
+        if (sp == 0) {
+            if (ei > n_entries) break;
+            cur = (uint32_t)__builtin_amdgcn_readlane((int)vlist, ei);
+            ++ei;
+        } else {
+            --sp;
+            const uint4 e = wstk[sp];
+            cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.x);
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.y);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.z);
+            inm = ((unsigned long long)hi << 32) | lo;
+        }
+        // ---- items whose own box is tested first ----
+        if (!(cur & rt::DESC_LEAF) && (cur & CUT_NODE_ENTRY) == CUT_NODE_ENTRY) {
+            // entry of a cut: a BLAS node whose own box is tested per ray (the reference tests it when it pops the
+            // node); lanes that pass walk on from it -- or, CUT_TRIM, test the triangles the next word names
+            SBox b;
+            uint32_t desc;
+            {
+                cdptr q = (cdptr)(const void*)(sc.nodes + (cur & CUT_NODE_IDX));
+                b.mnx = q[0];
+                b.mny = q[1];
+                b.mnz = q[2];
+                b.mxx = q[3];
+                b.mxy = q[4];
+                b.mxz = q[5];
+                if (cur & CUT_TRIM) {
+                    desc = (uint32_t)__builtin_amdgcn_readlane((int)vlist, ei);
+                    ++ei;
+                } else {
+                    desc = ((cuptr)(const void*)q)[15];
+                }
+            }
+            if (COUNT) wc.nodes += (unsigned)__builtin_popcountll(inm);
+            inm &= slab_rel<FAST, OCT>(b, ix, iy, iz);
+            cur = inm != 0ull ? desc : rt::DESC_NONE;
+        } else if (!(cur & rt::DESC_LEAF) && (cur & (rt::DESC_TLAS | rt::DESC_ROOT))) {
+            SBox b;
+            int32_t left, count, first;
+            uint32_t desc;
+            const bool tlas = (cur & rt::DESC_TLAS) != 0u;
+            if (tlas) {
+                sload_node(sc.tlas + (cur & 0x3FFFFFFFu), b, left, count, first, desc);
+            } else {
+                const RT_CONST int32_t* sr = (const RT_CONST int32_t*)(const void*)sc.slot_root;
+                const int32_t root = sr[cur & 0x1FFFFFFFu];
+                sload_node(sc.nodes + root, b, left, count, first, desc);  // walk into this BLAS
+            }
+            if (COUNT) wc.nodes += (unsigned)__builtin_popcountll(inm);
+            const unsigned long long hm = slab_rel<FAST, OCT>(b, ix, iy, iz) & inm;
+            if (tlas) {
+                if (hm != 0ull) {
+                    const uint32_t lo = (uint32_t)hm, hi = (uint32_t)(hm >> 32);
+                    if (left < 0) {
+                        for (int32_t k = count - 1; k >= 0; --k)
+                            wstk[sp++] = make_uint4(rt::DESC_ROOT | (uint32_t)(first + k), lo, hi, 0u);
+                    } else {
+                        wstk[sp++] = make_uint4(rt::DESC_TLAS | (uint32_t)(left + 1), lo, hi, 0u);
+                        wstk[sp++] = make_uint4(rt::DESC_TLAS | (uint32_t)left, lo, hi, 0u);
+                    }
+                }
+                cur = rt::DESC_NONE;
+            } else {
+                cur = hm != 0ull ? desc : rt::DESC_NONE;
+                inm = hm;
+            }
+        }
+        // ---- descend through internal BLAS nodes (the hot loop of a walk from the root) ----
         // One straight-line body with a single back edge: the scalar unit issues as slowly as the fp64
         // VALU (one instruction per SIMD every 4 cycles), so SALU instructions count like VALU ones.
-        // The next node / mask are scalar selects; `cur = DESC_NONE` when no lane hit either child.
+        // The next node / mask are scalar selects; `cur = DESC_NONE` (all bits) when no lane hit either child.
         while ((cur & (rt::DESC_LEAF | rt::DESC_TLAS | rt::DESC_ROOT)) == 0u) {
             // both children: the whole 128-byte pair as two 64-byte scalar loads at base + (cur << 6)
             // (host guarantees the node array is < 4 GB), tested unconditionally -- lanes outside `inm`
@@ -674,141 +821,8 @@ __device__ __forceinline__ void trace_packet(const PacketScene& sc, const unsign
             inm = (lnz != 0u) ? ml : mr;
             cur = ((lnz | rnz) != 0u) ? nxt : rt::DESC_NONE;
         }
-        const bool alive = cur != rt::DESC_NONE;
-        if (alive) {
-            if (cur & rt::DESC_LEAF) {
-                uint32_t first = cur & rt::DESC_TRI_MASK;
-                uint32_t cnt = ((cur >> 28) & 7u) + 1u;
-                if (cnt == 8u) {
-                    cuptr ext = (cuptr)(const void*)sc.leaf_ext;
-                    const uint32_t e = first;
-                    first = ext[2 * e];
-                    cnt = ext[2 * e + 1];
-                }
-                if (COUNT) {
-                    wc.tris += (unsigned long long)cnt * (unsigned)__builtin_popcountll(inm);
-                    wc.tri_steps += cnt;
-                }
-                const bool in = __builtin_amdgcn_inverse_ballot_w64(inm);
-                for (uint32_t k = 0; k < cnt; ++k) {
-                    // the whole 128-byte record in one round trip (both 64-byte lines requested together): staged
-                    // loads (edges, then tv/q, then tnum) put up to three dependent scalar-cache misses on the
-                    // wave's critical path per triangle
-                    u32x16 ta, tb;
-                    {
-                        const CamTri* trec = sc.tris + (size_t)(first + k);
-                        asm volatile(
-                            "s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)"
-                            : "=&s"(ta), "=&s"(tb)
-                            : "s"(trec)
-                            : "memory");
-                    }
-                    const double e0x = sgpr_f64(ta, 0), e0y = sgpr_f64(ta, 1), e0z = sgpr_f64(ta, 2);
-                    const double e2x = sgpr_f64(ta, 3), e2y = sgpr_f64(ta, 4), e2z = sgpr_f64(ta, 5);
-                    const double tvx = sgpr_f64(ta, 6), tvy = sgpr_f64(ta, 7), tvz = sgpr_f64(tb, 0);
-                    const double qx = sgpr_f64(tb, 1), qy = sgpr_f64(tb, 2), qz = sgpr_f64(tb, 3);
-                    const double tnum = sgpr_f64(tb, 4);
-                    // rtrayintersection.cpp:79-106, with the ray-independent parts precomputed
-                    const double px = dy * e2z - dz * e2y;
-                    const double py = dz * e2x - dx * e2z;
-                    const double pz = dx * e2y - dy * e2x;
-                    const double det = (e0x * px + e0y * py) + e0z * pz;
-                    bool need = in && det > 1e-6;
-                    double unum = 0.0, vnum = 0.0;
-                    if (need) {
-                        unum = (tvx * px + tvy * py) + tvz * pz;
-                        vnum = (dx * qx + dy * qy) + dz * qz;
-                        // Sure rejects, decided on the numerators so that a triangle none of the wave's rays can
-                        // hit costs no division: with 1e-6 < det < 2^700 (FAST: every |coordinate - camera| <
-                        // 1e100 and |direction| <= 1 bound det by 2.4e201) the rounded 1/det is a normal number
-                        // >= 2^-700 with relative error 2^-53, so
-                        //   num < -2^-300        =>  num * inv is a normal negative number: `>= 0` fails;
-                        //   unum + vnum > det * (1 + 2^-30)  =>  had both u in [0,1] and v >= 0 held, u + v would
-                        //                            exceed 1 by 2^-31, far beyond the four roundings involved.
-                        // NaNs compare false and take the full path.  Lanes that are not sure rejects compute
-                        // exactly what they did before, so results are unchanged.
-                        if (FAST) {
-                            const double lo = __builtin_fmin(unum, vnum);
-                            need = !(lo < -0x1p-300 || (unum + vnum) > det * (1.0 + 0x1p-30));
-                        }
-                    }
-                    if (need) {
-                        const double inv = 1.0 / det;
-                        const double u = unum * inv;
-                        const double v = vnum * inv;
-                        const double t = tnum * inv;
-                        const bool ok = (u >= 0.0) && (u <= 1.0) && (v >= 0.0) && ((u + v) <= 1.0) && (t >= 0.0) &&
-                                        (t <= __builtin_inf());
-                        if (ok && t < h.t) {
-                            h.t = t;
-                            h.u = u;
-                            h.v = v;
-                            h.prim = (int32_t)(first + k);
-                        }
-                    }
-                }
-            } else {
-                SBox b;
-                int32_t left, count, first;
-                uint32_t desc;
-                if ((cur & CUT_NODE_ENTRY) == CUT_NODE_ENTRY) {
-                    // entry of a cut: a BLAS node whose own box is tested per ray (the reference tests it when it
-                    // pops the node); lanes that pass walk on from it
-                    sload_node(sc.nodes + (cur & CUT_NODE_IDX), b, left, count, first, desc);
-                    if (COUNT) wc.nodes += (unsigned)__builtin_popcountll(inm);
-                    const unsigned long long hm = slab_rel<FAST, OCT>(b, ix, iy, iz) & inm;
-                    if (cur & CUT_TRIM) {
-                        // a leaf whose live triangles are named by the next word of the list (cut_trim)
-                        ++ei;
-                        desc = (uint32_t)__builtin_amdgcn_readlane((int)vlist, ei);
-                    }
-                    if (hm != 0ull) {
-                        cur = desc;
-                        inm = hm;
-                        continue;
-                    }
-                } else if (cur & rt::DESC_TLAS) {
-                    sload_node(sc.tlas + (cur & 0x3FFFFFFFu), b, left, count, first, desc);
-                    if (COUNT) wc.nodes += (unsigned)__builtin_popcountll(inm);
-                    const unsigned long long hm = slab_rel<FAST, OCT>(b, ix, iy, iz) & inm;
-                    if (hm != 0ull) {
-                        const uint32_t lo = (uint32_t)hm, hi = (uint32_t)(hm >> 32);
-                        if (left < 0) {
-                            for (int32_t k = count - 1; k >= 0; --k)
-                                wstk[sp++] = make_uint4(rt::DESC_ROOT | (uint32_t)(first + k), lo, hi, 0u);
-                        } else {
-                            wstk[sp++] = make_uint4(rt::DESC_TLAS | (uint32_t)(left + 1), lo, hi, 0u);
-                            wstk[sp++] = make_uint4(rt::DESC_TLAS | (uint32_t)left, lo, hi, 0u);
-                        }
-                    }
-                } else {
-                    const RT_CONST int32_t* sr = (const RT_CONST int32_t*)(const void*)sc.slot_root;
-                    const int32_t root = sr[cur & 0x1FFFFFFFu];
-                    sload_node(sc.nodes + root, b, left, count, first, desc);
-                    if (COUNT) wc.nodes += (unsigned)__builtin_popcountll(inm);
-                    const unsigned long long hm = slab_rel<FAST, OCT>(b, ix, iy, iz) & inm;
-                    if (hm != 0ull) {
-                        cur = desc;
-                        inm = hm;
-                        continue;  // walk into this BLAS
-                    }
-                }
-            }
-        }
-        // ---- pop ----
-        if (sp == 0) {
-            if (ei >= n_entries) break;
-            ++ei;  // next entry of the tile's cut: every valid lane takes part again
-            cur = (uint32_t)__builtin_amdgcn_readlane((int)vlist, ei);
-            inm = valid_mask;
-            continue;
-        }
-        --sp;
-        const uint4 e = wstk[sp];
-        cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.x);
-        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.y);
-        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.z);
-        inm = ((unsigned long long)hi << 32) | lo;
+        // ---- a leaf, or nothing ----
+        if (cur != rt::DESC_NONE) test_leaf<FAST, COUNT>(sc, cur, inm, dx, dy, dz, h, wc);
     }
 }
 
