@@ -605,15 +605,15 @@ constexpr uint32_t CUT_NODE_ENTRY = rt::DESC_TLAS | rt::DESC_ROOT;  // cut entry
 constexpr uint32_t CUT_TRIM = 0x10000000u;
 constexpr uint32_t CUT_NODE_IDX = 0x03FFFFFFu;
 
-// The triangles of a leaf descriptor (a count field of 8 names a range in leaf_ext) against the lanes of `inm`, in order, with the strict `<` on t of the reference (rtrayintersection.cpp:79-106).
+// The triangles of a leaf descriptor (EXT: a count field of 8 names a range in leaf_ext) against the lanes of `inm`, in order, with the strict `<` on t of the reference (rtrayintersection.cpp:79-106).
 // The records are addressed with a 32-bit scalar byte offset (the host sends scenes of >= 2^25 triangles to the
 // per-lane kernel): one add and one compare per triangle on the scalar unit, which is this kernel's busiest.
-template <bool FAST, bool COUNT>
+template <bool FAST, bool COUNT, bool EXT>
 __device__ __forceinline__ void test_leaf(const PacketScene& sc, const uint32_t leaf, const unsigned long long inm,
                                           const double dx, const double dy, const double dz, Hit& h, WaveCounters& wc) {
     uint32_t first = leaf & rt::DESC_TRI_MASK;
     uint32_t cnt = ((leaf >> 28) & 7u) + 1u;
-    if (cnt == 8u) {
+    if (EXT && cnt == 8u) {
         cuptr ext = (cuptr)(const void*)sc.leaf_ext;
         const uint32_t e = first;
         first = ext[2 * e];
@@ -690,7 +690,31 @@ template <bool FAST, int OCT, bool COUNT>
 __device__ __forceinline__ void trace_packet(const PacketScene& sc, const unsigned long long valid_mask,
                                           const double dx, const double dy, const double dz, const double ix,
                                           const double iy, const double iz, uint4* wstk, Hit& h, WaveCounters& wc,
-                                          const uint32_t vlist, int n_entries) {
+                                          const uint32_t vlist, int n_entries, const bool simple = false) {
+    if (simple) {
+        // CUT_SIMPLE list (cut_trim): nothing but leaves every ray reaches and trimmed leaves -- no stack, no
+        // dispatch: ~20 scalar instructions per entry
+        for (int e = 1; e <= n_entries; ++e) {
+            uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)vlist, e);
+            unsigned long long m = valid_mask;
+            if (!(w & rt::DESC_LEAF)) {
+                SBox b;
+                cdptr q = (cdptr)(const void*)(sc.nodes + (w & CUT_NODE_IDX));
+                b.mnx = q[0];
+                b.mny = q[1];
+                b.mnz = q[2];
+                b.mxx = q[3];
+                b.mxy = q[4];
+                b.mxz = q[5];
+                ++e;
+                w = (uint32_t)__builtin_amdgcn_readlane((int)vlist, e);
+                if (COUNT) wc.nodes += (unsigned)__builtin_popcountll(valid_mask);
+                m &= slab_rel<FAST, OCT>(b, ix, iy, iz);
+            }
+            if (m != 0ull) test_leaf<FAST, COUNT, false>(sc, w, m, dx, dy, dz, h, wc);
+        }
+        return;
+    }
     int sp = 0;
     int ei = 1;
     if (n_entries < 0) {
@@ -822,7 +846,7 @@ __device__ __forceinline__ void trace_packet(const PacketScene& sc, const unsign
             cur = ((lnz | rnz) != 0u) ? nxt : rt::DESC_NONE;
         }
         // ---- a leaf, or nothing ----
-        if (cur != rt::DESC_NONE) test_leaf<FAST, COUNT>(sc, cur, inm, dx, dy, dz, h, wc);
+        if (cur != rt::DESC_NONE) test_leaf<FAST, COUNT, true>(sc, cur, inm, dx, dy, dz, h, wc);
     }
 }
 
@@ -917,7 +941,8 @@ __device__ __forceinline__ void tile_coords(const int tile, const int n_tiles, c
 // =======================================================================================
 constexpr int CUT_WORDS = 32;                // header + entries per block (128 bytes)
 constexpr int CUT_CAP = CUT_WORDS - 1;       // entries
-constexpr uint32_t CUT_VALID = 0x80000000u;  // header: bit31 valid, bits 13..8 axis kinds (2 bits each), bits 7..0 entries
+constexpr uint32_t CUT_VALID = 0x80000000u;  // header: bit31 valid, bit 16 CUT_SIMPLE, bits 13..8 axis kinds (2 bits each), bits 7..0 entries
+constexpr uint32_t CUT_SIMPLE = 0x00010000u;  // header: every entry is a leaf (<= 7 triangles) or a CUT_TRIM pair (cut_trim)
 constexpr uint32_t CUT_NODE = rt::DESC_TLAS | rt::DESC_ROOT;  // entry: BLAS node (bits 25..0) tested per ray
 constexpr int CUT_THREADS = 64;  // one wave, 8 KB of LDS: fits the hole a retiring render workgroup (4 waves, 20 KB) leaves
 constexpr int CUT_MAX_LEVELS = 5;  // levels the render kernel reads: blocks of 1, 2, 4, 8, 16 pixels
@@ -1219,6 +1244,7 @@ __host__ __device__ inline void cut_trim(const CutArgs& a, const int tile, uint3
     if (!(slack < 1e100)) return;
     for (int i = 0; i < n; ++i) stk[i * stride] = out[1 + i];
     int w = 0;
+    bool simple = true;
     for (int i = 0; i < n; ++i) {
         const uint32_t e = stk[i * stride];
         const int rest = n - 1 - i;  // every later entry can do with one word
@@ -1236,6 +1262,7 @@ __host__ __device__ inline void cut_trim(const CutArgs& a, const int tile, uint3
         const uint32_t cnt = ((leaf >> 28) & 7u) + 1u;
         if (leaf == 0u || cnt == 8u) {  // not a leaf, or one with its range in leaf_ext: as it is
             out[1 + w++] = e;
+            simple = false;
             continue;
         }
         const uint32_t first = leaf & rt::DESC_TRI_MASK;
@@ -1246,13 +1273,13 @@ __host__ __device__ inline void cut_trim(const CutArgs& a, const int tile, uint3
         while (!((live >> hi) & 1u)) --hi;
         const uint32_t range = rt::DESC_LEAF | ((uint32_t)(hi - lo) << 28) | (first + (uint32_t)lo);
         if (per_ray) {
-            if (lo == 0 && hi == (int)cnt - 1) {
-                out[1 + w++] = e;
-            } else if (w + 2 + rest <= CUT_CAP) {
+            // (a leaf with every triangle live is written as a pair too: the list may then be CUT_SIMPLE)
+            if (w + 2 + rest <= CUT_CAP) {
                 out[1 + w++] = e | CUT_TRIM;
                 out[1 + w++] = range;
             } else {
                 out[1 + w++] = e;
+                simple = false;
             }
             continue;
         }
@@ -1274,7 +1301,7 @@ __host__ __device__ inline void cut_trim(const CutArgs& a, const int tile, uint3
             out[1 + w++] = range;
         }
     }
-    out[0] = (hdr & ~0xffu) | (uint32_t)w;
+    out[0] = (hdr & ~0xffu) | (uint32_t)w | (simple ? CUT_SIMPLE : 0u);
 }
 
 // One thread per block.  A wave takes an 8 x 8 patch of blocks (16 parents, neighbouring parts of the tree: its
@@ -1620,7 +1647,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 8), amdgp
                 switch (oct) {
 #define RT_OCT_CASE(O)                                                                                       \
     case O:                                                                                                  \
-        trace_packet<true, O, COUNT>(a.sc, amask, dx, dy, dz, ix, iy, iz, wstk, h, wc, cs.vcut, n_ent);     \
+        trace_packet<true, O, COUNT>(a.sc, amask, dx, dy, dz, ix, iy, iz, wstk, h, wc, cs.vcut, n_ent,      \
+                                     quick && (hdr0 & CUT_SIMPLE) != 0u);                                   \
         break;
                     RT_OCT_CASE(0)
                     RT_OCT_CASE(1)

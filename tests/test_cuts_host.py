@@ -17,6 +17,8 @@ from raytracer_amd import meshgen
 LEAF, TLAS, ROOT = 0x80000000, 0x40000000, 0x20000000
 NODE = TLAS | ROOT
 TRIM, NODE_IDX = 0x10000000, 0x03FFFFFF
+SIMPLE = 0x00010000  # header: the list holds nothing but leaves (<= 7 triangles) and TRIM pairs
+N_SIMPLE = [0]      # blocks with that promise seen by check_scene
 
 
 class Tree:
@@ -176,6 +178,20 @@ def check_scene(coords, colors, cam, H, W, spp, level, seed, timestep=0):
                 assert (inv[:, a] > 0).all() and (inv[:, a] < 1e100).all(), (b, a)
             elif kind == 1:
                 assert (inv[:, a] < 0).all() and (inv[:, a] > -1e100).all(), (b, a)
+        if hdr & SIMPLE:  # the render kernel then runs a loop that knows only these two kinds of entries
+            N_SIMPLE[0] += 1
+            ents = [int(e) for e in words[b, 1:1 + n]]
+            k = 0
+            while k < len(ents):
+                e = ents[k]
+                if e & LEAF:
+                    assert ((e >> 28) & 7) != 7, (b, hex(e))
+                    k += 1
+                else:
+                    assert (e & (NODE | TRIM)) == (NODE | TRIM) and k + 1 < len(ents), (b, hex(e))
+                    r = ents[k + 1]
+                    assert (r & LEAF) and ((r >> 28) & 7) != 7, (b, hex(r))
+                    k += 2
         tame = (np.abs(inv) < 1e100).all(axis=1)  # the kernel walks batches with other rays from the root
         ref = []
         walk_tlas(tree, 0, tame.copy(), cam_c, inv, ref)
@@ -300,11 +316,14 @@ def test_trimmed_leaves_drop_triangles_and_only_sure_misses(monkeypatch):
     c1, k1 = meshgen.uv_sphere(12, 16, radius=0.8, center=(0.2, 0.1, -1.5))  # closed surface: back faces
     H = W = 48
     cam = meshgen.camera_arrays(W, H, center=(0.1, 0.05, 0.4), target=(0.0, 0.0, -2.0), fov=60)
-    _, _, _, n_ref, n_cut = check_scene([c, c1], [k, k1], cam, H, W, 64, 1, seed=11)
+    N_SIMPLE[0] = 0
+    n_valid, _, _, n_ref, n_cut = check_scene([c, c1], [k, k1], cam, H, W, 64, 1, seed=11)
     assert n_cut < 0.7 * n_ref, (n_ref, n_cut)
+    assert N_SIMPLE[0] > 0.5 * n_valid, (N_SIMPLE[0], n_valid)  # most finest-level lists are leaves and pairs only
     monkeypatch.setenv("RT_NO_TRIM", "1")
+    N_SIMPLE[0] = 0
     _, _, _, n_ref2, n_cut2 = check_scene([c, c1], [k, k1], cam, H, W, 64, 1, seed=11)
-    assert n_ref2 == n_ref and n_cut2 == n_ref
+    assert n_ref2 == n_ref and n_cut2 == n_ref and N_SIMPLE[0] == 0
     monkeypatch.delenv("RT_NO_TRIM")
     monkeypatch.setenv("RT_CUT_LO", "0")  # per-pixel blocks
     _, _, _, n_ref0, n_cut0 = check_scene([c, c1], [k, k1], cam, H, W, 64, 0, seed=12)
