@@ -623,9 +623,12 @@ __device__ __forceinline__ void test_leaf(const PacketScene& sc, const uint32_t 
         wc.tris += (unsigned long long)cnt * (unsigned)__builtin_popcountll(inm);
         wc.tri_steps += cnt;
     }
-    const bool in = __builtin_amdgcn_inverse_ballot_w64(inm);
     uint32_t off = first << 7;  // sizeof(CamTri) == 128
-    const uint32_t end = off + (cnt << 7);
+    uint32_t end = off + (cnt << 7);
+    asm volatile("" : "+s"(end));  // (a trip count would cost a second counter)
+    // the lanes of `inm` (never empty) are the execution mask of the whole loop: each comparison's mask is then the
+    // next nesting level's as it is, without an AND with `inm` per triangle
+    if (!__builtin_amdgcn_inverse_ballot_w64(inm)) return;
     do {
         // the whole 128-byte record in one round trip (both 64-byte lines requested together): staged
         // loads (edges, then tv/q, then tnum) put up to three dependent scalar-cache misses on the
@@ -645,7 +648,7 @@ __device__ __forceinline__ void test_leaf(const PacketScene& sc, const uint32_t 
         const double py = dz * e2x - dx * e2z;
         const double pz = dx * e2y - dy * e2x;
         const double det = (e0x * px + e0y * py) + e0z * pz;
-        bool need = in && det > 1e-6;
+        bool need = det > 1e-6;
         double unum = 0.0, vnum = 0.0;
         if (need) {
             unum = (tvx * px + tvy * py) + tvz * pz;
