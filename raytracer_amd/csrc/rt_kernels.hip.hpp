@@ -596,8 +596,15 @@ struct WaveCounters {
 #ifndef RT_QUICK_DISPATCH
 #define RT_QUICK_DISPATCH 1
 #endif
+// Which port the one-pixel-per-batch instantiation's (wave-uniform) pixel arithmetic and cut address go to.  While
+// the entry lists cost ~530 scalar-side instructions per batch against ~485 vector ones, the vector unit was the
+// place (1: +0.8 % and +1 %, same box A/B); since the stack-free list loop (~310 against ~485) it is the scalar unit
+// again (0: +1.1 %).
+#ifndef RT_P64_VZERO
+#define RT_P64_VZERO 0
+#endif
 #ifndef RT_P64_VECTOR_CUT
-#define RT_P64_VECTOR_CUT 1
+#define RT_P64_VECTOR_CUT 0
 #endif
 constexpr uint32_t CUT_NODE_ENTRY = rt::DESC_TLAS | rt::DESC_ROOT;  // cut entry: BLAS node tested per ray (see "Tile cuts")
 // A CUT_NODE_ENTRY with this bit names a LEAF whose triangle range is overridden by the NEXT word of the list (a leaf
@@ -623,6 +630,11 @@ __device__ __forceinline__ void test_leaf(const PacketScene& sc, const uint32_t 
         wc.tris += (unsigned long long)cnt * (unsigned)__builtin_popcountll(inm);
         wc.tri_steps += cnt;
     }
+    // two of the test's fp64 literals live in VGPRs (spare) instead of SGPR pairs (spilled to VGPR lanes and read back
+    // with a vector instruction each, on the port this kernel is bound by)
+    double k_eps = 1e-6, k_neg = -0x1p-300;
+    asm("" : "+v"(k_eps));
+    asm("" : "+v"(k_neg));
     uint32_t off = first << 7;  // sizeof(CamTri) == 128
     uint32_t end = off + (cnt << 7);
     asm volatile("" : "+s"(end));  // (a trip count would cost a second counter)
@@ -648,7 +660,7 @@ __device__ __forceinline__ void test_leaf(const PacketScene& sc, const uint32_t 
         const double py = dz * e2x - dx * e2z;
         const double pz = dx * e2y - dy * e2x;
         const double det = (e0x * px + e0y * py) + e0z * pz;
-        bool need = det > 1e-6;
+        bool need = det > k_eps;
         double unum = 0.0, vnum = 0.0;
         if (need) {
             unum = (tvx * px + tvy * py) + tvz * pz;
@@ -664,7 +676,7 @@ __device__ __forceinline__ void test_leaf(const PacketScene& sc, const uint32_t 
             // exactly what they did before, so results are unchanged.
             if (FAST) {
                 const double lo = __builtin_fmin(unum, vnum);
-                need = !(lo < -0x1p-300 || (unum + vnum) > det * (1.0 + 0x1p-30));
+                need = !(lo < k_neg || (unum + vnum) > det * (1.0 + 0x1p-30));
             }
         }
         if (need) {
@@ -1479,10 +1491,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 8), amdgp
     auto fetch = [&](const int base) {
         Slot q;
         const int rr = base + lane;
-        // P64: wave-uniform -- but carried in a VGPR (an opaque zero is added), so that the Morton decode, the bounds
-        // test and the sample index below are vector instructions: since the cuts the kernel issues more scalar
-        // than vector instructions per batch, and the scalar unit issues no faster (same box, A/B: 0.8 %)
-        const int ml = P64 ? (base >> (6 + lg64)) + vzero : rr / spp;
+        // P64: wave-uniform (RT_P64_VZERO: carried in a VGPR all the same, by adding an opaque zero, so that the
+        // Morton decode, the bounds test and the sample index below are vector instructions; see the macro)
+        const int ml = P64 ? (base >> (6 + lg64)) + (RT_P64_VZERO ? vzero : 0) : rr / spp;
         const int k = P64 ? (base & (spp - 1)) + lane : rr - ml * spp;
         const int m = wave_pixel(ml, wv, m0, a.interleave);
         q.px = tx0 + (int)compact1by1((uint32_t)m);
