@@ -1655,6 +1655,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 8), amdgp
                 oct = (ngx != 0ull ? 1 : 0) | (ngy != 0ull ? 2 : 0) | (ngz != 0ull ? 4 : 0);
                 any_risky = __builtin_amdgcn_ballot_w64(risky) != 0ull;
             }
+            // (a count >= 0 is the header's own: the batch takes the block's list as it is)
+            const bool simple = n_ent >= 0 && (hdr0 & CUT_SIMPLE) != 0u && a.fast_ok == 2;
             if (any_risky) {
                 trace_packet<false, -1, COUNT>(a.sc, amask, dx, dy, dz, ix, iy, iz, wstk, h, wc, 0u, -1);
             } else if (uni) {
@@ -1662,7 +1664,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 8), amdgp
 #define RT_OCT_CASE(O)                                                                                       \
     case O:                                                                                                  \
         trace_packet<true, O, COUNT>(a.sc, amask, dx, dy, dz, ix, iy, iz, wstk, h, wc, cs.vcut, n_ent,      \
-                                     quick && (hdr0 & CUT_SIMPLE) != 0u);                                   \
+                                     simple);                                                               \
         break;
                     RT_OCT_CASE(0)
                     RT_OCT_CASE(1)
@@ -1677,7 +1679,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 8), amdgp
             } else {
                 // mixed signs: the general slab test (min/max per axis), every product finite
                 trace_packet<true, -1, COUNT>(a.sc, amask, dx, dy, dz, ix, iy, iz, wstk, h, wc, cs.vcut,
-                                              a.fast_ok == 2 ? n_ent : -1);
+                                              a.fast_ok == 2 ? n_ent : -1, simple);
             }
             if (COUNT && lane == 0) {
                 w_nodes += wc.nodes;

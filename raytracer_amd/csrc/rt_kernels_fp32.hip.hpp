@@ -188,13 +188,82 @@ __device__ __forceinline__ unsigned long long slab32(const float b0, const float
 
 __device__ __forceinline__ float u2f(const uint32_t u) { return __builtin_bit_cast(float, u); }
 
+// The triangles of a leaf descriptor against the lanes of `inm` (see rtk::test_leaf), in binary32.
+template <bool COUNT>
+__device__ __forceinline__ void test_leaf32(const Packet32Args& sc, const uint32_t leaf, const unsigned long long inm,
+                                            const float dx, const float dy, const float dz, Hit32& h,
+                                            rtk::WaveCounters& wc) {
+    uint32_t first = leaf & rt::DESC_TRI_MASK;
+    uint32_t cnt = ((leaf >> 28) & 7u) + 1u;
+    if (cnt == 8u) {
+        rtk::cuptr ext = (rtk::cuptr)(const void*)sc.leaf_ext;
+        const uint32_t e = first;
+        first = ext[2 * e];
+        cnt = ext[2 * e + 1];
+    }
+    if (COUNT) wc.tris += (unsigned long long)cnt * (unsigned)__builtin_popcountll(inm);
+    const bool in = __builtin_amdgcn_inverse_ballot_w64(inm);
+    for (uint32_t k = 0; k < cnt; ++k) {
+        rtk::u32x16 tr;  // the whole 64-byte record in one scalar round trip
+        {
+            const Tri32* trec = sc.tris + (size_t)(first + k);
+            asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tr) : "s"(trec) : "memory");
+        }
+        const float e0x = u2f(tr[0]), e0y = u2f(tr[1]), e0z = u2f(tr[2]);
+        const float e2x = u2f(tr[3]), e2y = u2f(tr[4]), e2z = u2f(tr[5]);
+        const float px = dy * e2z - dz * e2y;
+        const float py = dz * e2x - dx * e2z;
+        const float pz = dx * e2y - dy * e2x;
+        const float det = (e0x * px + e0y * py) + e0z * pz;
+        if (in && det > 1e-6f) {
+            const float tvx = u2f(tr[6]), tvy = u2f(tr[7]), tvz = u2f(tr[8]);
+            const float qx = u2f(tr[9]), qy = u2f(tr[10]), qz = u2f(tr[11]);
+            const float tnum = u2f(tr[12]);
+            const float unum = (tvx * px + tvy * py) + tvz * pz;
+            const float vnum = (dx * qx + dy * qy) + dz * qz;
+            // sure rejects on the numerators (see rtk::test_leaf): a triangle that none of the
+            // wave's rays can hit costs no reciprocal and no range checks
+            if (!(__builtin_fminf(unum, vnum) < -0x1p-60f || (unum + vnum) > det * (1.0f + 0x1p-18f))) {
+                const float inv = __builtin_amdgcn_rcpf(det);
+                const float u = unum * inv;
+                const float v = vnum * inv;
+                const float t = tnum * inv;
+                const bool ok = (u >= 0.0f) && (u <= 1.0f) && (v >= 0.0f) && ((u + v) <= 1.0f) && (t >= 0.0f);
+                if (ok && t < h.t) {
+                    h.t = t;
+                    h.u = u;
+                    h.v = v;
+                    h.prim = (int32_t)(first + k);
+                }
+            }
+        }
+    }
+}
+
 // Same wave-packet walk as rtk::trace_packet (reference visit order, no culling), in binary32.
 template <int OCT, bool COUNT>
 __device__ __forceinline__ void trace_packet32(const Packet32Args& sc, const unsigned long long valid_mask,
                                                const float dx, const float dy, const float dz, const float ix,
                                                const float iy, const float iz, uint4* wstk, Hit32& h,
-                                               rtk::WaveCounters& wc, const uint32_t vlist, int n_entries) {
+                                               rtk::WaveCounters& wc, const uint32_t vlist, int n_entries,
+                                               const bool simple) {
     const f2 ixy = f2{ix, iy}, izx = f2{iz, ix}, iyz = f2{iy, iz};
+    if (simple) {
+        // CUT_SIMPLE list (rtk::cut_trim): leaves every ray reaches and trimmed leaves only -- no stack, no dispatch
+        for (int e = 1; e <= n_entries; ++e) {
+            uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)vlist, e);
+            unsigned long long m = valid_mask;
+            if (!(w & rt::DESC_LEAF)) {
+                cfptr q = (cfptr)(const void*)(sc.nodes + (w & rtk::CUT_NODE_IDX));
+                ++e;
+                w = (uint32_t)__builtin_amdgcn_readlane((int)vlist, e);
+                if (COUNT) wc.nodes += (unsigned)__builtin_popcountll(valid_mask);
+                m &= slab32<OCT>(q[0], q[1], q[2], q[3], q[4], q[5], ixy, izx, iyz);
+            }
+            if (m != 0ull) test_leaf32<COUNT>(sc, w, m, dx, dy, dz, h, wc);
+        }
+        return;
+    }
     int sp = 0;
     int ei = 1;  // entry list of the batch's cut, as in rtk::trace_packet (n_entries < 0: walk from the root)
     uint32_t cur = rt::DESC_TLAS;
@@ -233,52 +302,7 @@ __device__ __forceinline__ void trace_packet32(const Packet32Args& sc, const uns
         const bool alive = cur != rt::DESC_NONE;
         if (alive) {
             if (cur & rt::DESC_LEAF) {
-                uint32_t first = cur & rt::DESC_TRI_MASK;
-                uint32_t cnt = ((cur >> 28) & 7u) + 1u;
-                if (cnt == 8u) {
-                    rtk::cuptr ext = (rtk::cuptr)(const void*)sc.leaf_ext;
-                    const uint32_t e = first;
-                    first = ext[2 * e];
-                    cnt = ext[2 * e + 1];
-                }
-                if (COUNT) wc.tris += (unsigned long long)cnt * (unsigned)__builtin_popcountll(inm);
-                const bool in = __builtin_amdgcn_inverse_ballot_w64(inm);
-                for (uint32_t k = 0; k < cnt; ++k) {
-                    rtk::u32x16 tr;  // the whole 64-byte record in one scalar round trip
-                    {
-                        const Tri32* trec = sc.tris + (size_t)(first + k);
-                        asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tr) : "s"(trec) : "memory");
-                    }
-                    const float e0x = u2f(tr[0]), e0y = u2f(tr[1]), e0z = u2f(tr[2]);
-                    const float e2x = u2f(tr[3]), e2y = u2f(tr[4]), e2z = u2f(tr[5]);
-                    const float px = dy * e2z - dz * e2y;
-                    const float py = dz * e2x - dx * e2z;
-                    const float pz = dx * e2y - dy * e2x;
-                    const float det = (e0x * px + e0y * py) + e0z * pz;
-                    if (in && det > 1e-6f) {
-                        const float tvx = u2f(tr[6]), tvy = u2f(tr[7]), tvz = u2f(tr[8]);
-                        const float qx = u2f(tr[9]), qy = u2f(tr[10]), qz = u2f(tr[11]);
-                        const float tnum = u2f(tr[12]);
-                        const float unum = (tvx * px + tvy * py) + tvz * pz;
-                        const float vnum = (dx * qx + dy * qy) + dz * qz;
-                        // sure rejects on the numerators (see rtk::trace_packet): a triangle that none of the
-                        // wave's rays can hit costs no reciprocal and no range checks
-                        if (!(__builtin_fminf(unum, vnum) < -0x1p-60f || (unum + vnum) > det * (1.0f + 0x1p-18f))) {
-                            const float inv = __builtin_amdgcn_rcpf(det);
-                            const float u = unum * inv;
-                            const float v = vnum * inv;
-                            const float t = tnum * inv;
-                            const bool ok =
-                                (u >= 0.0f) && (u <= 1.0f) && (v >= 0.0f) && ((u + v) <= 1.0f) && (t >= 0.0f);
-                            if (ok && t < h.t) {
-                                h.t = t;
-                                h.u = u;
-                                h.v = v;
-                                h.prim = (int32_t)(first + k);
-                            }
-                        }
-                    }
-                }
+                test_leaf32<COUNT>(sc, cur, inm, dx, dy, dz, h, wc);
             } else if ((cur & rtk::CUT_NODE_ENTRY) == rtk::CUT_NODE_ENTRY) {
                 // entry of a cut: a BLAS node whose own box is tested per ray
                 const uint32_t ni = cur & rtk::CUT_NODE_IDX;
@@ -458,12 +482,14 @@ __global__ __launch_bounds__(NT, 8) void render_packet32_kernel(const Packet32Ar
             const int n_ent = __builtin_amdgcn_ballot_w64(wild) != 0ull
                                   ? -1
                                   : rtk::batch_cut_entries(cs.vcut, amask, ngx, ngy, ngz, cs.jit.x, cs.jit.y);
+            // (a count >= 0 is the header's own: the batch takes the block's list as it is)
+            const bool simple = n_ent >= 0 && ((uint32_t)__builtin_amdgcn_readfirstlane((int)cs.vcut) & rtk::CUT_SIMPLE) != 0u;
             if (uni) {
                 const int oct = (ngx != 0ull ? 1 : 0) | (ngy != 0ull ? 2 : 0) | (ngz != 0ull ? 4 : 0);
                 switch (oct) {
 #define RT_OCT32_CASE(O)                                                                    \
     case O:                                                                                 \
-        trace_packet32<O, COUNT>(a, amask, dx, dy, dz, ix, iy, iz, wstk, h, wc, cs.vcut, n_ent); \
+        trace_packet32<O, COUNT>(a, amask, dx, dy, dz, ix, iy, iz, wstk, h, wc, cs.vcut, n_ent, simple); \
         break;
                     RT_OCT32_CASE(0)
                     RT_OCT32_CASE(1)
@@ -476,7 +502,7 @@ __global__ __launch_bounds__(NT, 8) void render_packet32_kernel(const Packet32Ar
 #undef RT_OCT32_CASE
                 }
             } else {
-                trace_packet32<-1, COUNT>(a, amask, dx, dy, dz, ix, iy, iz, wstk, h, wc, cs.vcut, n_ent);
+                trace_packet32<-1, COUNT>(a, amask, dx, dy, dz, ix, iy, iz, wstk, h, wc, cs.vcut, n_ent, simple);
             }
             if (COUNT && lane == 0) {
                 w_nodes += wc.nodes;
