@@ -523,8 +523,8 @@ def main():
                                      "frac_alone": scalar_instr / (alone_ms * 1e-3) / (1024 * 2.4e9 / 4)
                                      if scalar_instr and alone_ms else None,
                                      "frac": scalar_instr / (kms * 1e-3) / (1024 * 2.4e9 / 4) if scalar_instr else None,
-                                     "note": "per batch the kernel issues about as many scalar-side as vector instructions; "
-                                             "both ports take one instruction per SIMD every 4 cycles"},
+                                     "note": "SALU + branch + SMEM instructions of the kernel; the scalar port, like the vector port, "
+                                             "takes one instruction per SIMD every 4 cycles"},
                     "gpu_step": {"lane_ops_per_step": step_ops, "by_kernel": step_kernels,
                                  "ms_per_step": elapsed / args.steps * 1e3,
                                  "achieved": step_ops / (elapsed / args.steps) / 1e12 if step_ops else None,
