@@ -160,6 +160,7 @@ struct rt_ctx {
     struct StagedSet {
         BackScene b;
         hipStream_t stream = nullptr;
+        bool owns_stream = false;
         hipEvent_t last_use = nullptr;  // after a swap: last render on the buffers this set now holds
         bool used = false;
         int state = 0;  // 0 free, 1 being filled, 2 staged
@@ -614,7 +615,15 @@ int ensure_staged_pool(rt_ctx* c, size_t n) {
     std::lock_guard<std::mutex> lk(c->staged_mu);
     while (c->staged.size() < n) {
         std::unique_ptr<rt_ctx::StagedSet> st(new rt_ctx::StagedSet());
-        HIP_TRY(hipStreamCreateWithFlags(&st->stream, hipStreamNonBlocking));
+        // RT_STAGE_STREAMS=1: one stream per set; default: the first NSTAGE_STREAMS sets' streams are shared by the
+        // rest -- the number of HIP streams of a context then does not grow with RT_BUILD_AHEAD
+        const size_t n_own = std::getenv("RT_STAGE_STREAMS") ? ~size_t(0) : size_t(1);
+        if (c->staged.size() < n_own) {
+            HIP_TRY(hipStreamCreateWithFlags(&st->stream, hipStreamNonBlocking));
+            st->owns_stream = true;
+        } else {
+            st->stream = c->staged[c->staged.size() % n_own]->stream;
+        }
         HIP_TRY(hipEventCreateWithFlags(&st->last_use, hipEventDisableTiming));
         c->staged.push_back(std::move(st));
     }
@@ -950,7 +959,7 @@ void rt_destroy(rt_ctx* c) {
         st->b.tris.release();
         st->b.colors.release();
         if (st->last_use) (void)hipEventDestroy(st->last_use);
-        if (st->stream) (void)hipStreamDestroy(st->stream);
+        if (st->stream && st->owns_stream) (void)hipStreamDestroy(st->stream);
     }
     c->staged.clear();
     c->back.nodes.release();
