@@ -1354,9 +1354,12 @@ void adapt_streams(rt_ctx* c, int rows, int W, int spp) {
     const double render_ms = c->stats.render_kernel_ms;
     if (!(sampler_ms > 0.f) || !(render_ms > 0.0)) return;
     const char* re = std::getenv("RT_ADAPT_RATIO");  // (test knob)
-    const double ratio = re ? std::max(1e-6, std::atof(re)) : 0.8;
+    // (0.95, was 0.8: the sampler's workgroups hold wave slots and its jumps are work, so the fewer streams the
+    // better as long as the fill still ends before the traversal it hides behind -- 4096^2 x 64: 21.0 -> 20.5 ms per
+    // step, same box; rounding up to a multiple of 64 streams is the margin)
+    const double ratio = re ? std::max(1e-6, std::atof(re)) : 0.95;
     double want = double(sl.states_n) * double(sampler_ms) / (ratio * render_ms);
-    want = std::min(1024.0, std::max(256.0, std::ceil(want / 64.0) * 64.0));
+    want = std::min(1024.0, std::max(128.0, std::ceil(want / 64.0) * 64.0));
     if (c->adapt_job.valid()) {
         if (c->adapt_job.wait_for(std::chrono::seconds(0)) != std::future_status::ready) return;
         try {

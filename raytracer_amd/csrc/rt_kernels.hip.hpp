@@ -603,6 +603,9 @@ struct WaveCounters {
 #ifndef RT_P64_VZERO
 #define RT_P64_VZERO 0
 #endif
+#ifndef RT_P64_FRESH_ARGS
+#define RT_P64_FRESH_ARGS 1
+#endif
 #ifndef RT_P64_VECTOR_CUT
 #define RT_P64_VECTOR_CUT 0
 #endif
@@ -1493,9 +1496,23 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 8), amdgp
         const int rr = base + lane;
         // P64: wave-uniform (RT_P64_VZERO: carried in a VGPR all the same, by adding an opaque zero, so that the
         // Morton decode, the bounds test and the sample index below are vector instructions; see the macro)
-        const int ml = P64 ? (base >> (6 + lg64)) + (RT_P64_VZERO ? vzero : 0) : rr / spp;
-        const int k = P64 ? (base & (spp - 1)) + lane : rr - ml * spp;
-        const int m = wave_pixel(ml, wv, m0, a.interleave);
+        // P64: the launch constants this arithmetic needs are read from the kernel arguments HERE, every batch (scalar
+        // loads + a few SALU instructions): kept across the traversal they were spilled to VGPR lanes, and each
+        // v_readlane is an issue slot of the vector port, which is the busier one (RT_P64_FRESH_ARGS, same box A/B)
+        int lgq = lg64, ilv = a.interleave;
+        if (P64 && RT_P64_FRESH_ARGS) {
+            const auto kseg = __builtin_amdgcn_kernarg_segment_ptr();
+            int p64v;
+            asm volatile("s_load_dword %0, %2, %3\n\ts_load_dword %1, %2, %4\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&s"(p64v), "=&s"(ilv)
+                         : "s"(kseg), "i"(offsetof(PacketArgs, pair64)), "i"(offsetof(PacketArgs, interleave))
+                         : "memory");
+            lgq = p64v - 1;
+        }
+        const int sppq = P64 ? (64 << lgq) : spp;
+        const int ml = P64 ? (base >> (6 + lgq)) + (RT_P64_VZERO ? vzero : 0) : rr / spp;
+        const int k = P64 ? (base & (sppq - 1)) + lane : rr - ml * spp;
+        const int m = wave_pixel(ml, wv, m0, ilv);
         q.px = tx0 + (int)compact1by1((uint32_t)m);
         q.py = ty0 + (int)compact1by1((uint32_t)m >> 1);
         // P64 with 32 < a.spp < 64 (host: pair64 = 1): one pixel per batch all the same, lanes a.spp.. idle -- their
@@ -1524,6 +1541,25 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 8), amdgp
             const uint32_t blk = (uint32_t)(q.py >> a.cut_lo) * ctx + (uint32_t)(q.px >> a.cut_lo);
             const uint32_t* const cp = reinterpret_cast<const uint32_t*>(base_ptr) + (size_t)blk * CUT_WORDS;
             if (lane < CUT_WORDS && q.px < a.W && q.py < a.rows) q.vcut = cp[lane];
+        } else if (P64 && RT_P64_FRESH_ARGS) {
+            // one pixel per batch: the cut is the finest level's (cut_eff[cut_lo] == cut_lo: it is always made)
+            const auto kseg = __builtin_amdgcn_kernarg_segment_ptr();
+            int lo;
+            asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(lo) : "s"(kseg), "i"(offsetof(PacketArgs, cut_lo)) : "memory");
+            const int pxs = __builtin_amdgcn_readfirstlane(q.px), pys = __builtin_amdgcn_readfirstlane(q.py);
+            if (lo >= 0 && pxs < a.W && pys < a.rows) {
+                unsigned long long base_ptr;
+                uint32_t ctx;
+                const uint32_t o1 = (uint32_t)offsetof(PacketArgs, cut_lvl) + 8u * (uint32_t)lo;
+                const uint32_t o2 = (uint32_t)offsetof(PacketArgs, cut_tx) + 4u * (uint32_t)lo;
+                asm volatile("s_load_dwordx2 %0, %2, %3\n\ts_load_dword %1, %2, %4\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&s"(base_ptr), "=&s"(ctx)
+                             : "s"(kseg), "s"(o1), "s"(o2)
+                             : "memory");
+                const uint32_t* const cp = reinterpret_cast<const uint32_t*>(base_ptr) +
+                                           ((size_t)(pys >> lo) * ctx + (size_t)(pxs >> lo)) * CUT_WORDS;
+                if (__builtin_amdgcn_inverse_ballot_w64(0xFFFFFFFFull)) q.vcut = cp[lane];  // lanes 0 .. CUT_WORDS - 1
+            }
         } else if (a.cut_lo >= 0) {
             const int last = min(63, n_rays - 1 - base);
             const int mf = __builtin_amdgcn_readfirstlane(m), ml2 = P64 ? mf : __builtin_amdgcn_readlane(m, last);
