@@ -876,3 +876,127 @@ ORC_API int orc_quantise(const double pc[3], int spp, double *intensity) {
     if (intensity) *intensity = inten;
     return (int)(uint8_t)(int)(inten * 255.99);
 }
+
+/* ------------------------------------------------------------------------ */
+/* Treeless checker (round 3).  Built ONLY from the probe-pinned primitives: */
+/* the ray of a sample (orc_pixel_sample + orc_normalized, pinned against    */
+/* the reference's Eigen expressions) and one row of intersect_bvh_triangles */
+/* (moller_trumbore, pinned likewise).  No tree, no builder, no walk: for    */
+/* every ray the minimum t over ALL triangles in the order given, the first  */
+/* index that attains it (Eigen minCoeff's strict-< scan,                    */
+/* rtrayintersection.cpp:173) and how many attain it.  A hit id that equals  */
+/* this argmin does not depend on either BVH builder or on either traversal. */
+/* ------------------------------------------------------------------------ */
+#include <pthread.h>
+
+/* t of moller_trumbore() with the invalid cases returned early.  Same operations in the same order on the
+ * values that reach the result; pinned against moller_trumbore() itself by tests/test_oracle_pins.py. */
+static inline double mt_t_edges(const double o[3], const double d[3], const double *v0, const double *e0,
+                                const double *e2) {
+    double p[3], tv[3], q[3];
+    p[0] = d[1] * e2[2] - d[2] * e2[1];
+    p[1] = d[2] * e2[0] - d[0] * e2[2];
+    p[2] = d[0] * e2[1] - d[1] * e2[0];
+    double det = (e0[0] * p[0] + e0[1] * p[1]) + e0[2] * p[2];
+    if (!(det > 1e-6)) return INFINITY;
+    double inv = 1.0 / det;
+    for (int j = 0; j < 3; ++j) tv[j] = o[j] - v0[j];
+    double u = ((tv[0] * p[0] + tv[1] * p[1]) + tv[2] * p[2]) * inv;
+    if (!((u >= 0) && (u <= 1))) return INFINITY;
+    q[0] = tv[1] * e0[2] - tv[2] * e0[1];
+    q[1] = tv[2] * e0[0] - tv[0] * e0[2];
+    q[2] = tv[0] * e0[1] - tv[1] * e0[0];
+    double v = ((d[0] * q[0] + d[1] * q[1]) + d[2] * q[2]) * inv;
+    if (!((v >= 0) && ((u + v) <= 1))) return INFINITY;
+    double t = ((e2[0] * q[0] + e2[1] * q[1]) + e2[2] * q[2]) * inv;
+    if (!((t >= 0.0) && (t <= INFINITY))) return INFINITY;
+    return t;
+}
+/* the two edge vectors depend on the triangle alone (rtrayintersection.cpp:64-72): the brute-force loop
+ * computes them once per triangle -- the same two subtractions, so the same bits -- instead of once per ray */
+static inline void mt_edges(const double *tri, double *rec /* v0, e0, e2 */) {
+    for (int j = 0; j < 3; ++j) {
+        rec[j] = tri[j];
+        rec[3 + j] = tri[3 + j] - tri[j];
+        rec[6 + j] = tri[6 + j] - tri[j];
+    }
+}
+static inline double mt_t_only(const double o[3], const double d[3], const double *tri) {
+    double rec[9];
+    mt_edges(tri, rec);
+    return mt_t_edges(o, d, rec, rec + 3, rec + 6);
+}
+ORC_API double orc_mt_t_only(const double o[3], const double d[3], const double tri[9]) {
+    return mt_t_only(o, d, tri);
+}
+
+typedef struct {
+    int64_t r0, r1, n_tris;
+    const double *origins;
+    int64_t origin_stride; /* 0: one origin for all rays, 3: one per ray */
+    const double *dirs, *tris;
+    double *out_t;
+    int32_t *out_first, *out_nmin;
+} brute_job;
+
+static void *brute_worker(void *arg) {
+    brute_job *jb = (brute_job *)arg;
+    for (int64_t r = jb->r0; r < jb->r1; ++r) {
+        const double *o = jb->origins + r * jb->origin_stride;
+        const double *d = jb->dirs + 3 * r;
+        double best = INFINITY;
+        int32_t first = -1, nmin = 0;
+        for (int64_t k = 0; k < jb->n_tris; ++k) {
+            const double *rec = jb->tris + 9 * k; /* v0, e0, e2 */
+            double t = mt_t_edges(o, d, rec, rec + 3, rec + 6);
+            if (t < best) {
+                best = t;
+                first = (int32_t)k;
+                nmin = 1;
+            } else if (t == best && t != INFINITY) {
+                ++nmin;
+            }
+        }
+        jb->out_t[r] = best;
+        jb->out_first[r] = first;
+        if (jb->out_nmin) jb->out_nmin[r] = nmin;
+    }
+    return NULL;
+}
+
+/* origins: 3 doubles (origin_stride 0) or n_rays*3 (origin_stride 3); tris: n_tris*9 in the caller's order.
+ * out_first = -1 and out_t = +inf for a ray no triangle accepts. */
+ORC_API void orc_brute_force(int64_t n_rays, const double *origins, int origin_stride, const double *dirs,
+                             int64_t n_tris, const double *tris, double *out_t, int32_t *out_first,
+                             int32_t *out_nmin, int n_threads) {
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 64) n_threads = 64;
+    pthread_t th[64];
+    brute_job jobs[64];
+    double *recs = (double *)malloc((size_t)(n_tris ? n_tris : 1) * 9 * sizeof(double));
+    for (int64_t k = 0; k < n_tris; ++k) mt_edges(tris + 9 * k, recs + 9 * k);
+    for (int i = 0; i < n_threads; ++i) {
+        jobs[i] = (brute_job){n_rays * i / n_threads, n_rays * (i + 1) / n_threads, n_tris, origins,
+                              origin_stride, dirs, recs, out_t, out_first, out_nmin};
+        if (i + 1 < n_threads) pthread_create(&th[i], NULL, brute_worker, &jobs[i]);
+    }
+    brute_worker(&jobs[n_threads - 1]);
+    for (int i = 0; i + 1 < n_threads; ++i) pthread_join(th[i], NULL);
+    free(recs);
+}
+
+/* The rays render_ppm_image shoots (rtrender.cpp:53-58) for rows [row0,row1), sample order (j,i,k), from the
+ * offsets (ox,oy) = random_double()-0.5 given in `jitter` (relative to row0): the two pinned primitives, nothing
+ * else. */
+ORC_API void orc_ray_dirs(const double cam[3], const double p00[3], const double sp[6], int W, int spp, int row0,
+                          int row1, const double *jitter, double *out_dirs) {
+    size_t smp = 0;
+    for (int j = row0; j < row1; ++j)
+        for (int i = 0; i < W; ++i)
+            for (int k = 0; k < spp; ++k, ++smp) {
+                double ps[3], dd[3];
+                orc_pixel_sample(p00, sp, i, j, jitter[2 * smp], jitter[2 * smp + 1], ps);
+                for (int c = 0; c < 3; ++c) dd[c] = ps[c] - cam[c];
+                orc_normalized(dd, out_dirs + 3 * smp);
+            }
+}

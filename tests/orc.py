@@ -60,6 +60,10 @@ def _load():
     lib.orc_shade_sky.argtypes = [C.c_double, _f64p]
     lib.orc_quantise.restype = C.c_int
     lib.orc_quantise.argtypes = [_f64p, C.c_int, C.POINTER(C.c_double)]
+    lib.orc_mt_t_only.restype = C.c_double
+    lib.orc_mt_t_only.argtypes = [_f64p, _f64p, _f64p]
+    lib.orc_brute_force.argtypes = [C.c_int64, _f64p, C.c_int, _f64p, C.c_int64, _f64p, _f64p, _i32p, _i32p, C.c_int]
+    lib.orc_ray_dirs.argtypes = [_f64p, _f64p, _f64p, C.c_int, C.c_int, C.c_int, C.c_int, _f64p, _f64p]
     return lib
 
 
@@ -186,3 +190,48 @@ class Scene:
                             C.byref(nn), C.byref(nt), C.byref(nh))
         return dict(rgb=rgb, intensity=inten, hit_mesh=hm, hit_elem=he, hit_t=ht, nodes=nn.value, tris=nt.value,
                     hits=nh.value)
+
+
+# ---- treeless checker: no tree, no builder, no walk -- only the probe-pinned primitives ----------------------
+def n_threads():
+    """Threads for the brute-force checker: the cores this process may run on, at most 16 (the GPU box's share)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(16, n))
+
+
+def jitter_stream(n_samples, rng=None):
+    """(ox, oy) = random_double() - 0.5 pairs in stream order (rtrender.cpp:53), flat array of 2*n_samples."""
+    rng = Rng() if rng is None else rng
+    return rng.doubles(2 * int(n_samples)) - 0.5
+
+
+def ray_dirs(cam, p00, spacing, W, spp, jitter, row0=0, row1=None):
+    """Directions of the rays render_ppm_image shoots for rows [row0,row1) from the given offsets, order (j,i,k)."""
+    jitter = np.ascontiguousarray(jitter, np.float64).reshape(-1)
+    n = jitter.size // 2
+    if row1 is None:
+        row1 = row0 + n // (W * spp)
+    assert (row1 - row0) * W * spp == n
+    out = np.empty((n, 3))
+    lib.orc_ray_dirs(np.ascontiguousarray(cam, np.float64).reshape(3), np.ascontiguousarray(p00, np.float64).reshape(3),
+                     np.ascontiguousarray(spacing, np.float64).reshape(6), W, spp, row0, row1, jitter, out)
+    return out
+
+
+def brute_force(origin, dirs, tris, threads=None):
+    """Closest hit of every ray over ALL triangles (n,3,3) in the order given: (t, first index attaining it or -1,
+    number of triangles attaining it).  origin: (3,) shared or (n,3)."""
+    dirs = np.ascontiguousarray(dirs, np.float64).reshape(-1, 3)
+    tris = np.ascontiguousarray(tris, np.float64).reshape(-1, 9)
+    o = np.ascontiguousarray(origin, np.float64).reshape(-1)
+    stride = 0 if o.size == 3 else 3
+    assert stride == 0 or o.size == dirs.size
+    n = dirs.shape[0]
+    t = np.empty(n)
+    first = np.empty(n, np.int32)
+    nmin = np.empty(n, np.int32)
+    lib.orc_brute_force(n, o, stride, dirs, tris.shape[0], tris, t, first, nmin, threads or n_threads())
+    return t, first, nmin
