@@ -416,35 +416,54 @@ def main():
         jms, hjm = st1["jitter_kernel_ms"], st1["host_jump_ms"]
         # kernel time: the timed steps' own launches (HIP events on the kernel's stream)
         kms = kernel_ms_timed if kernel_ms_timed else st1["render_kernel_ms"]
+        # visit counters, twice: (a) the walk the TIMED kernel does -- from the pixel blocks' cuts, DESIGN 4.2a -- which
+        # is what the roofline below prices; (b) the reference's visit rule (walk from node 0, every ray on its own),
+        # which is what SURVEY 8(d)'s B_ray is defined on and is kept only under `reference_visit_rule`
         frame(0, counters=True)
         ctx.sync()
-        cs = ctx.stats()
+        ref_cs = ctx.stats()
+        os.environ["RT_COUNT_WITH_CUTS"] = "1"
+        try:
+            frame(0, counters=True)
+            ctx.sync()
+            cs = ctx.stats()
+        finally:
+            os.environ.pop("RT_COUNT_WITH_CUTS", None)
         rays = cs["rays"]
-        bray = b_ray(cs["nodes_visited"], cs["tris_tested"], cs["rays_hit"], rays, spp)
-        # (1) SURVEY 8(d)'s figure: per-RAY algorithmic bytes (every ray charged 64 B per node it visits).  The
-        #     packet kernel fetches a node once per 64-ray WAVE through the scalar cache, so this is a model of
-        #     the reference's visit rule, not a bound on this kernel: its "fraction" exceeds 1.
-        hbm_alg = {"bytes_per_ray": bray, "bytes_per_launch": bray * rays_per_frame,
-                   "achieved_gbs": rays_per_frame * bray / (kms * 1e-3) / 1e9, "peak_gbs": HBM_PEAK_GBS,
-                   "frac": rays_per_frame * bray / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                   "note": "SURVEY 8(d) B_ray is per ray; the kernel fetches node/triangle records per 64-ray wave, "
-                           "so frac > 1 says the model is not a bound here, not that work was skipped"}
-        # (2) the same figure per WAVE: records the waves actually request (64 B per node, 128 B per camera-
-        #     relative triangle record) + the per-ray streams (jitter in, hit id out, colour, intensity)
-        wave_bytes = (cs["wave_node_fetches"] * 64.0 + cs["wave_tri_fetches"] * 128.0 +
+        bray = b_ray(ref_cs["nodes_visited"], ref_cs["tris_tested"], ref_cs["rays_hit"], rays, spp)
+        reference_visit_rule = {
+            "nodes_per_ray": ref_cs["nodes_visited"] / rays, "tris_per_ray": ref_cs["tris_tested"] / rays,
+            "b_ray_bytes": bray, "bytes_per_launch": bray * rays_per_frame,
+            "gbs_at_kernel_time": rays_per_frame * bray / (kms * 1e-3) / 1e9,
+            "x_hbm_peak": rays_per_frame * bray / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "note": "SURVEY 8(d)'s B_ray charges every RAY 64 B per node and 72 B per triangle it visits when it walks "
+                    "from node 0 alone.  The timed kernel does not do that work (one scalar fetch per 64-ray wave, walk "
+                    "started at the block's cut), so this is a model of the reference's visit rule and NOT a bound on "
+                    "the kernel: x_hbm_peak > 1 by design.  Counted by a separate root-walk launch."}
+        # bytes the timed kernel's waves really request (cut walk): 64 B per node record, 128 B per camera-relative
+        # triangle record, 128 B per cut list + the per-ray streams (jitter in, hit id out, colour, intensity)
+        wave_bytes = (cs["wave_node_fetches"] * 64.0 + cs["wave_tri_fetches"] * 128.0 + (rays / 64.0) * 128.0 +
                       rays * (16.0 + (4.0 if want_ids else 0.0) + 8.0 / spp) + cs["rays_hit"] * 24.0)
         hbm_wave = {"bytes_per_launch": wave_bytes, "achieved_gbs": wave_bytes / (kms * 1e-3) / 1e9,
                     "peak_gbs": HBM_PEAK_GBS, "frac": wave_bytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    "node_records_per_ray": cs["wave_node_fetches"] / rays,
-                    "tri_records_per_ray": cs["wave_tri_fetches"] / rays,
-                    "note": "requested by the waves (scalar cache / L2 / MALL absorb most of it); an upper bound on "
-                            "what can reach HBM.  Counted, like nodes_per_ray / tris_per_ray, by the COUNT instantiation, "
-                            "which walks from the root under the reference's visit rule: the timed kernel starts at "
-                            "the blocks' cuts and fetches fewer node records than this"}
-        # (3) what binds: fp64 VALU issue.  Instruction count from the committed PMC pass of THESE kernels
-        #     (source hash must match), time from this run.
-        # the same kernel with the GPU to itself (no look-ahead sampler, prep / cut kernels in front of it instead of
-        # beside the previous launch): what the sharing in the timed steps costs it
+                    "node_records_per_batch": cs["wave_node_fetches"] / (rays / 64.0),
+                    "tri_records_per_batch": cs["wave_tri_fetches"] / (rays / 64.0),
+                    "box_tests_per_ray": cs["nodes_visited"] / rays, "tri_tests_per_ray": cs["tris_tested"] / rays,
+                    "note": "counted on the cut walk (RT_COUNT_WITH_CUTS=1), i.e. by the walk the timed kernel does; "
+                            "requested by the waves -- scalar cache / L2 / MALL absorb part of it, `traffic` is what "
+                            "reached HBM"}
+        # ALGORITHMIC work of a launch in fp64 lane-operations: what the frame needs under the cut walk, priced at the
+        # leanest correctly rounded instruction sequences (DESIGN 4.2 "necessary work"), independent of how the kernel
+        # is written: masked-off lanes, scalar bookkeeping moved to the vector unit, spills etc. are NOT in it.
+        nec_parts = {
+            # 2 int->f64, 2 adds (sample position), 12 pixel sample, 3 dd, 5 squared norm, 10 sqrt (v_rsq + Goldschmidt),
+            # 5 refined reciprocal of the norm + 3 x 3 quotients, 3 x 7 reciprocals of the direction (slab test)
+            "ray_generation": 69.0 * rays,
+            "box_tests": 12.0 * cs["nodes_visited"],  # 6 mul + 3 max + 2 min + 1 cmp (octant-specialised slab test)
+            "triangle_tests": 28.0 * cs["tris_tested"],  # camera-relative record: p, det, u/v numerators, rejects
+            "shading": 17.0 * cs["rays_hit"] + 12.0 * (rays - cs["rays_hit"]),  # w + 3 x (3 mul + 2 add) | sky
+            "in_order_sum": 3.0 * rays + 16.0 * (rays / spp)}  # 3 adds per sample; luma, /spp, *255.99, cvt per pixel
+        necessary = sum(nec_parts.values())
         alone_ms = None
         try:
             if args.lean:  # profiling runs: the trace should hold the timed launches and little else
@@ -464,6 +483,7 @@ def main():
             os.environ.pop("RT_NO_PREP_OVERLAP", None)
         traffic = None
         lane_ops = None
+        active_lane_ops = None
         step_ops = None
         step_kernels = None
         scalar_instr = None
@@ -480,9 +500,12 @@ def main():
                     pmc_note = f"profiles/pmc_{args.workload}.json is for another frame shape"
                 else:
                     traffic = pmc.get("hbm_bytes_per_launch")
-                    vi = pmc.get(pmc.get("dominant_kernel", ""), {}).get("SQ_INSTS_VALU")
-                    lane_ops = vi * 64 if vi else None
                     dom = pmc.get(pmc.get("dominant_kernel", ""), {})
+                    vi = dom.get("SQ_INSTS_VALU")
+                    lane_ops = vi * 64 if vi else None
+                    # SQ_THREAD_CYCLES_VALU = sum over VALU instructions of their ACTIVE lanes (x 4 cycles on the 16-lane
+                    # SIMD is already folded out by rocprofv3's unit: it reports lane-instructions): lanes under EXEC
+                    active_lane_ops = dom.get("SQ_THREAD_CYCLES_VALU")
                     if all(k in dom for k in ("SQ_INSTS_SALU", "SQ_INSTS_BRANCH", "SQ_INSTS_SMEM")):
                         scalar_instr = dom["SQ_INSTS_SALU"] + dom["SQ_INSTS_BRANCH"] + dom["SQ_INSTS_SMEM"]
                     # every kernel of a steady-state step (they share the GPU with each other): launches per step x
@@ -498,43 +521,65 @@ def main():
                             if key in name:
                                 step_kernels[key] = rec["SQ_INSTS_VALU"] * 64.0 * mult
                     step_ops = sum(step_kernels.values()) if step_kernels else None
-                    pmc_note = f"profiles/pmc_{args.workload}.json (SQ_INSTS_VALU x 64; FETCH_SIZE/WRITE_SIZE passes)"
+                    pmc_note = (f"profiles/pmc_{args.workload}.json (SQ_INSTS_VALU x 64, SQ_THREAD_CYCLES_VALU; "
+                                f"FETCH_SIZE/WRITE_SIZE passes)")
             except Exception as e:
                 pmc_note = f"profiles/pmc_{args.workload}.json unreadable: {e}"
         else:
             pmc_note = f"no profiles/pmc_{args.workload}.json: run profiles/run_prof.sh <tag> {args.workload}"
-        achieved = lane_ops / (kms * 1e-3) / 1e12 if lane_ops else None
-        roofline = {"bound": "fp64_valu_issue", "achieved": achieved, "peak": FP64_LANE_OPS_PEAK / 1e12,
-                    "unit": "T lane-ops/s", "frac": achieved / (FP64_LANE_OPS_PEAK / 1e12) if achieved else None,
-                    "traffic": traffic,
+        peak_t = FP64_LANE_OPS_PEAK / 1e12
+        achieved = necessary / (kms * 1e-3) / 1e12
+
+        def rate(ops, ms):
+            return ops / (ms * 1e-3) / 1e12 if ops and ms else None
+
+        def frac(ops, ms):
+            return ops / (ms * 1e-3) / FP64_LANE_OPS_PEAK if ops and ms else None
+
+        roofline = {"bound": "fp64_valu_issue", "achieved": achieved, "peak": peak_t, "unit": "T lane-ops/s",
+                    "frac": achieved / peak_t, "traffic": traffic,
+                    "what": "achieved = ALGORITHMIC fp64 lane-operations of one launch (`necessary`, below) / the kernel's "
+                            "average duration in the timed steps; frac = distance from the work the frame needs.  The "
+                            "instructions the kernel really issues are under `issue` (a busy-ness figure: it rises when "
+                            "instructions are added)",
                     "kernel": "rtk::render_packet_kernel", "kernel_ms": kms,
                     "kernel_ms_source": ("HIP events of the %d timed launches" % args.steps) if kernel_ms_timed
                     else "HIP events of one launch after the timed loop",
-                    "lane_ops_per_launch": lane_ops, "counters_from": pmc_note,
-                    "note": "kernel_ms is the kernel's duration in the timed steps, where it shares the GPU with the next "
-                            "frame's sampler, prep and cut kernels (all VALU work): kernel_alone is the same kernel with "
-                            "the GPU to itself, gpu_step counts every kernel of a step against the step's time",
-                    "kernel_alone": {"kernel_ms": alone_ms,
-                                     "achieved": lane_ops / (alone_ms * 1e-3) / 1e12 if lane_ops and alone_ms else None,
-                                     "frac": lane_ops / (alone_ms * 1e-3) / FP64_LANE_OPS_PEAK if lane_ops and alone_ms else None},
+                    "necessary": {"lane_ops_per_launch": necessary, "lane_ops_per_ray": necessary / rays,
+                                  "by_part": nec_parts,
+                                  "box_tests_per_ray": cs["nodes_visited"] / rays,
+                                  "tri_tests_per_ray": cs["tris_tested"] / rays, "hit_rate": cs["rays_hit"] / rays,
+                                  "counts_from": "RT_COUNT_WITH_CUTS=1 launch of this run (the timed kernel's own walk)"},
+                    "efficiency": necessary / lane_ops if lane_ops else None,  # necessary / executed (x64)
+                    "efficiency_vs_active_lanes": necessary / active_lane_ops if active_lane_ops else None,
+                    "issue": {"executed_lane_ops_x64": lane_ops, "active_lane_ops": active_lane_ops,
+                              "active_lanes_per_instruction": active_lane_ops / (lane_ops / 64.0)
+                              if lane_ops and active_lane_ops else None,
+                              "frac_x64": frac(lane_ops, kms), "frac_active_lanes": frac(active_lane_ops, kms),
+                              "counters_from": pmc_note,
+                              "note": "x64 counts every issue slot, masked-off lanes included (port busy-ness); "
+                                      "active lanes = SQ_THREAD_CYCLES_VALU (lanes under EXEC)"},
+                    "kernel_alone": {"kernel_ms": alone_ms, "achieved": rate(necessary, alone_ms),
+                                     "frac": frac(necessary, alone_ms), "issue_frac_x64": frac(lane_ops, alone_ms),
+                                     "issue_frac_active_lanes": frac(active_lane_ops, alone_ms),
+                                     "note": "the same kernel with the GPU to itself (no look-ahead sampler, prep / cut "
+                                             "kernels in front of it instead of beside the previous launch)"},
                     # the other issue port: SALU + branch + SMEM instructions of the kernel against one instruction per
                     # SIMD per 4 cycles (1024 SIMDs x 2.4 GHz / 4)
                     "scalar_issue": {"instructions_per_launch": scalar_instr, "peak_ginstr_s": 1024 * 2.4 / 4,
                                      "frac_alone": scalar_instr / (alone_ms * 1e-3) / (1024 * 2.4e9 / 4)
                                      if scalar_instr and alone_ms else None,
-                                     "frac": scalar_instr / (kms * 1e-3) / (1024 * 2.4e9 / 4) if scalar_instr else None,
-                                     "note": "SALU + branch + SMEM instructions of the kernel; the scalar port, like the vector port, "
-                                             "takes one instruction per SIMD every 4 cycles"},
-                    "gpu_step": {"lane_ops_per_step": step_ops, "by_kernel": step_kernels,
+                                     "frac": scalar_instr / (kms * 1e-3) / (1024 * 2.4e9 / 4) if scalar_instr else None},
+                    "gpu_step": {"lane_ops_per_step_x64": step_ops, "by_kernel": step_kernels,
                                  "ms_per_step": elapsed / args.steps * 1e3,
-                                 "achieved": step_ops / (elapsed / args.steps) / 1e12 if step_ops else None,
-                                 "frac": step_ops / (elapsed / args.steps) / FP64_LANE_OPS_PEAK if step_ops else None},
+                                 "issue_frac_x64": step_ops / (elapsed / args.steps) / FP64_LANE_OPS_PEAK if step_ops else None,
+                                 "necessary_frac": necessary / (elapsed / args.steps) / FP64_LANE_OPS_PEAK,
+                                 "note": "every kernel of a step (traversal, sampler, jumps, prep, cuts) against the step's "
+                                         "wall time; necessary_frac = the frame's algorithmic work / step time / peak"},
                     "peak_note": "256 CU x 4 SIMD x 16 lanes x 2.4 GHz, no fma (-ffp-contract=off is the parity contract)",
                     "rays_per_launch": rays_per_frame, "kernel_only_mrays_s": rays_per_frame / (kms * 1e-3) / 1e6,
-                    "nodes_per_ray": cs["nodes_visited"] / rays, "tris_per_ray": cs["tris_tested"] / rays,
-                    "hit_rate": cs["rays_hit"] / rays,
                     "hbm_measured_frac": traffic / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic else None,
-                    "hbm_algorithmic": hbm_alg, "hbm_per_wave": hbm_wave}
+                    "hbm_per_wave": hbm_wave, "reference_visit_rule": reference_visit_rule}
         # host hand-over cost (PCIe, page-locked host buffers), never part of `value`
         frame(0)
         ctx.sync()

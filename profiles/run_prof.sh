@@ -9,7 +9,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_${TAG}_${WL}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $REPO/bench.py --workload $WL --steps 8 --warmup 4 --lean"
+BENCH="python3 $REPO/bench.py --workload $WL --steps 20 --warmup 5 --lean"   # the driver's step counts: the trace average and ms_per_step are comparable
 BENCH1="python3 $REPO/bench.py --workload $WL --steps 1 --warmup 0 --lean"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/trace.log" 2>&1 || { echo "trace pass failed"; tail -5 "$OUT/trace.log"; exit 1; }
 echo "trace pass ok"

@@ -235,3 +235,21 @@ def brute_force(origin, dirs, tris, threads=None):
     nmin = np.empty(n, np.int32)
     lib.orc_brute_force(n, o, stride, dirs, tris.shape[0], tris, t, first, nmin, threads or n_threads())
     return t, first, nmin
+
+
+def ray_dirs_segment(cam, p00, spacing, spp, j, i0, npix, jitter):
+    """Directions of the samples of pixels (j, i0 .. i0+npix-1), from their offsets `jitter` (npix*spp pairs): the same
+    two pinned primitives as ray_dirs, for checks on a few stretches of a frame too large to brute-force whole."""
+    cam = np.ascontiguousarray(cam, np.float64).reshape(3)
+    p00 = np.ascontiguousarray(p00, np.float64).reshape(3)
+    sp = np.ascontiguousarray(spacing, np.float64).reshape(6)
+    jitter = np.ascontiguousarray(jitter, np.float64).reshape(-1, 2)
+    assert jitter.shape[0] == npix * spp
+    out = np.empty((npix * spp, 3))
+    ps = np.empty(3)
+    d = np.empty(3)
+    for n in range(npix * spp):
+        lib.orc_pixel_sample(p00, sp, i0 + n // spp, j, float(jitter[n, 0]), float(jitter[n, 1]), ps)
+        lib.orc_normalized(ps - cam, d)
+        out[n] = d
+    return out

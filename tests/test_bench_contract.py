@@ -33,8 +33,32 @@ def test_committed_bench_line_follows_the_contract(path):
         assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
         assert r["frac"] == pytest.approx(r["achieved"] / r["peak"])
         assert r["achieved"] == pytest.approx(r["rays_per_launch"] * r["bytes_per_ray"] / (r["kernel_ms"] * 1e-3) / 1e9, rel=1e-6)
+    elif "necessary" in r:
+        # round 3: `achieved` is the frame's ALGORITHMIC lane-operations (necessary work under the cut walk) over the
+        # kernel's time -- distance from necessary work; the executed instructions (x64, active lanes) are under `issue`
+        assert r["bound"] == "fp64_valu_issue" and r["unit"] == "T lane-ops/s"
+        assert r["peak"] == pytest.approx(256 * 4 * 16 * 2.4e9 / 1e12)
+        n = r["necessary"]
+        assert n["lane_ops_per_launch"] == pytest.approx(sum(n["by_part"].values()))
+        assert r["achieved"] == pytest.approx(n["lane_ops_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e12, rel=1e-9)
+        assert r["frac"] == pytest.approx(r["achieved"] / r["peak"]) and 0.0 < r["frac"] <= 1.0
+        i = r["issue"]
+        if i["executed_lane_ops_x64"] is not None:  # null (with counters_from saying why) when the PMC summary is stale
+            assert r["efficiency"] == pytest.approx(n["lane_ops_per_launch"] / i["executed_lane_ops_x64"])
+            assert 0.0 < r["efficiency"] <= 1.0 and r["frac"] <= i["frac_active_lanes"] <= i["frac_x64"] <= 1.0
+            assert 1.0 <= i["active_lanes_per_instruction"] <= 64.0
+        else:
+            assert i["counters_from"]
+        w, v = r["hbm_per_wave"], r["reference_visit_rule"]
+        assert "nodes_per_ray" not in r and "hbm_algorithmic" not in r  # root-walk figures live under reference_visit_rule
+        assert w["box_tests_per_ray"] == n["box_tests_per_ray"] <= v["nodes_per_ray"]
+        assert w["frac"] == pytest.approx(w["bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9 / 8000.0, rel=1e-6)
+        if r["traffic"] is not None:
+            assert r["hbm_measured_frac"] == pytest.approx(r["traffic"] / (r["kernel_ms"] * 1e-3) / 1e9 / 8000.0, rel=1e-6)
+            assert r["hbm_measured_frac"] <= 1.0
+        assert d["config"]["host_threads_per_rank"] >= 1
     else:
-        # what binds the kernel is fp64 VALU issue; the HBM figures are kept beside it
+        # round 2: executed instructions x 64 against the fp64 VALU issue peak (a busy-ness figure, superseded)
         assert r["bound"] == "fp64_valu_issue" and r["unit"] == "T lane-ops/s"
         assert r["peak"] == pytest.approx(256 * 4 * 16 * 2.4e9 / 1e12)
         if r["achieved"] is not None:  # null (with counters_from saying why) when the PMC summary is stale

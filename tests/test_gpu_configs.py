@@ -69,6 +69,28 @@ def test_c4_oracle_rows_at_exact_stream_positions(c4):
     assert set(np.unique(pm[sample[sample >= 0]])) == {0, 1, 2, 3}
 
 
+def test_c4_hit_ids_against_the_treeless_argmin(c4):
+    """Builder- and walk-independent: for 12 stretches of 8 pixels x 64 samples spread over the frame, the reported hit
+    is the closest of ALL 5,005,448 triangles by the probe-pinned Moller-Trumbore row (tests/test_treeless.py)."""
+    H, W, spp, cam, out = c4["H"], c4["W"], c4["spp"], c4["cam"], c4["out"]
+    tri = np.concatenate([c[0] for c in c4["coords"]])
+    base = np.cumsum([0] + [c.shape[1] for c in c4["coords"]])
+    rs = np.random.default_rng(4)
+    n_hit = 0
+    for j, i0 in zip(rs.integers(300, H - 300, 12), rs.integers(300, W - 308, 12)):
+        s0 = (int(j) * W + int(i0)) * spp
+        rng = orc.Rng()
+        rng.set_state(ra.mt19937_state_at(s0 * 4))
+        dirs = orc.ray_dirs_segment(*cam, spp, int(j), int(i0), 8, rng.doubles(8 * spp * 2) - 0.5)
+        bt, first, nmin = orc.brute_force(cam[0], dirs, tri)
+        mesh, elem = c4["host"].map_prims(out["hit_prim"][s0:s0 + 8 * spp])
+        got = np.where(mesh >= 0, base[np.maximum(mesh, 0)] + elem, -1)
+        ok = (got == first) | ((nmin > 1) & (got >= 0))
+        assert ok.all() and np.array_equal(bits(bt), bits(out["hit_t"][s0:s0 + 8 * spp])), (j, i0)
+        n_hit += int((first >= 0).sum())
+    assert n_hit > 0.8 * 12 * 8 * spp
+
+
 def test_c4_packet_kernel_equals_per_lane_kernel(c4):
     H, W, spp, cam, ctx, out = c4["H"], c4["W"], c4["spp"], c4["cam"], c4["ctx"], c4["out"]
     os.environ["RT_FORCE_PERLANE"] = "1"

@@ -49,6 +49,24 @@ def test_oracle_rows_at_exact_stream_positions(big):
         assert np.array_equal(big["out"]["rgb"][r], w["rgb"][0]), r
 
 
+def test_hit_ids_against_the_treeless_argmin(big):
+    """Builder- and walk-independent: 24 stretches of 64 pixels x 8 samples, closest of ALL 1,048,352 triangles."""
+    H, W, spp, cam, out = big["H"], big["W"], big["spp"], big["cam"], big["out"]
+    rs = np.random.default_rng(7)
+    n_hit = 0
+    for j, i0 in zip(rs.integers(0, H, 24), rs.integers(0, W - 64, 24)):
+        s0 = (int(j) * W + int(i0)) * spp
+        rng = orc.Rng()
+        rng.set_state(ra.mt19937_state_at(s0 * 4))
+        dirs = orc.ray_dirs_segment(*cam, spp, int(j), int(i0), 64, rng.doubles(64 * spp * 2) - 0.5)
+        bt, first, nmin = orc.brute_force(cam[0], dirs, big["c"][0])
+        _, elem = big["host"].map_prims(out["hit_prim"][s0:s0 + 64 * spp])
+        ok = (elem == first) | ((nmin > 1) & (elem >= 0))
+        assert ok.all() and np.array_equal(bits(bt), bits(out["hit_t"][s0:s0 + 64 * spp])), (j, i0)
+        n_hit += int((first >= 0).sum())
+    assert n_hit > 0.5 * 24 * 64 * spp
+
+
 def test_idempotent_and_band_decomposition(big):
     H, W, spp, cam, ctx = big["H"], big["W"], big["spp"], big["cam"], big["ctx"]
     ctx.rng_seed(5489)
