@@ -74,6 +74,10 @@ typedef struct {
     double build_seconds;
 } rt_scene_info_t;
 int rt_scene_info(const rt_scene *scene, rt_scene_info_t *out);
+/* Test seam, host-only.  The builder partitions long ranges (>= 65,536 elements) with a chunk-parallel closed form of
+ * the reference's sequential two-pointer loop (cpp/rtbvh.cpp:271-285); this runs both on `cases` random class patterns
+ * of up to max_n elements with random chunk lengths and returns how many differ (0 = identical permutations). */
+int64_t rt_partition_selftest(int64_t cases, uint64_t seed, int max_n);
 
 /* Introspection of the host tree in the reference's own numbering (parity tests). */
 int rt_scene_tlas(const rt_scene *scene, double *boxes6, int32_t *blas_count, int32_t *left,

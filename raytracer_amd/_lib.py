@@ -55,6 +55,7 @@ _PROTOS = {
     "rt_version": (C.c_char_p, []),
     "rt_device_count": (C.c_int, []),
     "rt_host_threads": (C.c_int, []),
+    "rt_partition_selftest": (C.c_int64, [C.c_int64, C.c_uint64, C.c_int]),
     "rt_host_alloc": (_VP, [C.c_size_t]),
     "rt_host_free": (None, [_VP]),
     "rt_scene_build": (_VP, [C.c_int, C.POINTER(_VP), C.POINTER(_VP), _VP, C.c_int, C.c_int]),

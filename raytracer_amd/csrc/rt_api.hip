@@ -661,6 +661,13 @@ const char* rt_last_error(void) { return g_err.c_str(); }
 const char* rt_version(void) { return "rtgpu 0.1 (gfx950, fp64 parity path)"; }
 
 int rt_host_threads(void) { return rt::host_threads(); }
+int64_t rt_partition_selftest(int64_t cases, uint64_t seed, int max_n) {
+    try {
+        return rt::partition_selftest(cases, seed, max_n);
+    } catch (const std::exception& e) {
+        return fail(RT_E_INVALID, e.what());
+    }
+}
 
 void* rt_host_alloc(size_t bytes) {
     void* p = nullptr;

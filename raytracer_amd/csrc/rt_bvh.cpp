@@ -392,6 +392,150 @@ bool no_zero_component(const Box& b) {
     return true;
 }
 
+// ---- the reference's two-pointer partition (rtbvh.cpp:271-285) as a data-parallel pass: SAME permutation ----
+// The loop `while (mid < end) { if (left(mid)) ++mid; else swap(idx[mid], idx[--end]); }` is sequential, but the
+// permutation it produces has a closed form.  Positions (mid, end) always hold their original elements (swaps write
+// only positions mid and end), so with nl = number of left-class elements, S = first + nl, E = first + count:
+//   * a left-class element originally below S is examined in place and never moves;
+//   * every right-class element below S ("hole" k = 1..A, ascending) is thrown to the top of the unexamined range and
+//     the loop then pulls elements down from the top until a left-class one arrives: hole k receives the k-th
+//     left-class element of [S, E) counted from the END (positions q_1 > q_2 > ... > q_A; A holes, A such elements);
+//   * a right-class element pulled on the way lands one position below where it was (r -> r - 1), and the element
+//     thrown out of hole k lands just above that run: at q_{k-1} - 1 (q_0 = E);
+//   * what is left when mid reaches S is a run [S, q_A) of right-class elements (q_A = E when A = 0): the loop
+//     rotates it -- the element at S goes to q_A - 1, the others move down by one.
+// So every element's destination follows from two prefix sums (right-class below S, left-class from the end), the
+// passes below are chunk-parallel, and the result equals the serial loop's element for element -- which matters:
+// leaves keep their triangles in this order (rtbvh.cpp:515-536) and ties in t go to the first (rtrayintersection.cpp
+// :173-177).  rt_partition_selftest compares the two on random class patterns; tests/test_bvh_build.py on whole trees.
+template <class IsLeft, class Run>
+int64_t partition_closed_form(int32_t* idx, Rec* rec, int64_t first, int64_t count, int64_t chunk, const IsLeft& is_left,
+                              const Run& run) {
+    const int64_t E = first + count, nc = (count + chunk - 1) / chunk;
+    std::vector<uint8_t> flag(static_cast<size_t>(count));  // 1 = left-class, by ORIGINAL position
+    std::vector<int64_t> cl(static_cast<size_t>(nc)), pa(static_cast<size_t>(nc) + 1, 0), sb(static_cast<size_t>(nc) + 1, 0);
+    run(nc, [&](int64_t c) {
+        const int64_t lo = first + c * chunk, hi = std::min(E, lo + chunk);
+        int64_t n = 0;
+        for (int64_t i = lo; i < hi; ++i) n += (flag[i - first] = is_left(i) ? 1 : 0);
+        cl[c] = n;
+    });
+    int64_t nl = 0;
+    for (int64_t c = 0; c < nc; ++c) nl += cl[c];
+    const int64_t S = first + nl;
+    // pa[c] = right-class elements below S in chunks before c; sb[c] = left-class elements at or above S in chunks after c
+    for (int64_t c = 0; c < nc; ++c) {
+        const int64_t lo = first + c * chunk, hi = std::min(E, lo + chunk);
+        int64_t a;
+        if (hi <= S) {
+            a = (hi - lo) - cl[c];
+        } else if (lo >= S) {
+            a = 0;
+        } else {
+            a = 0;
+            for (int64_t i = lo; i < S; ++i) a += 1 - flag[i - first];
+        }
+        pa[c + 1] = pa[c] + a;
+    }
+    for (int64_t c = nc - 1; c >= 0; --c) {
+        const int64_t lo = first + c * chunk, hi = std::min(E, lo + chunk);
+        int64_t b;
+        if (lo >= S) {
+            b = cl[c];
+        } else if (hi <= S) {
+            b = 0;
+        } else {
+            b = 0;
+            for (int64_t i = S; i < hi; ++i) b += flag[i - first];
+        }
+        sb[c] = sb[c + 1] + b;  // sb[c] here = left-class at or above S in chunks c.. ; chunk c's own start at sb[c + 1]
+    }
+    const int64_t A = pa[nc];
+    if (A != sb[0]) throw std::runtime_error("internal: partition hole / filler counts differ");
+    if (E == S) return nl;  // everything is left-class: the loop moves nothing
+    // In place.  Pass 1: the elements thrown out of the holes are saved (x), and q is filled.  Pass 2: every chunk
+    // of [S, E) sweeps its positions ASCENDING and moves old[r] to its destination -- r - 1 for a right-class element
+    // (already read by this chunk, or the last position of the chunk below: that one write is deferred to pass 3),
+    // hole k for the left-class element at q_k, whose place-below q_k - 1 then takes x_{k+1}.  The element at S, if
+    // right-class, and x_1 go to the tops of their runs, which may lie in other chunks: deferred too.
+    std::vector<int64_t> hole(static_cast<size_t>(A)), q(static_cast<size_t>(A));
+    std::vector<int32_t> x_idx(static_cast<size_t>(A));
+    std::vector<Rec> x_rec(rec ? static_cast<size_t>(A) : 0);
+    run(nc, [&](int64_t c) {
+        const int64_t lo = first + c * chunk, hi = std::min(E, lo + chunk);
+        int64_t j = pa[c];
+        for (int64_t i = lo; i < std::min(hi, S); ++i)
+            if (!flag[i - first]) {
+                hole[j] = i;
+                x_idx[j] = idx[i];
+                if (rec) x_rec[j] = rec[i];
+                ++j;
+            }
+        j = sb[c + 1];
+        for (int64_t i = hi - 1; i >= std::max(lo, S); --i)
+            if (flag[i - first]) q[j++] = i;
+    });
+    struct Late {  // one deferred write per chunk (+ the two run tops)
+        int64_t dst = -1;
+        int32_t idx = 0;
+        Rec rec;
+    };
+    std::vector<Late> late(static_cast<size_t>(nc) + 2);
+    auto put = [&](int64_t dst, int32_t v, const Rec* r) {
+        idx[dst] = v;
+        if (rec) rec[dst] = *r;
+    };
+    run(nc, [&](int64_t c) {
+        const int64_t lo = std::max(first + c * chunk, S), hi = std::min(E, first + (c + 1) * chunk);
+        if (lo >= hi) return;
+        // rank (1-based, from the end) of the next left-class element at or above lo: those above this chunk + this chunk's
+        int64_t k = sb[c + 1];
+        for (int64_t i = lo; i < hi; ++i) k += flag[i - first];
+        for (int64_t r = lo; r < hi; ++r) {
+            const int32_t v = idx[r];
+            const Rec* rr = rec ? &rec[r] : nullptr;
+            if (flag[r - first]) {  // r == q_k: to hole k; x_{k+1} lands just below it (if there is a hole k + 1)
+                const int64_t kk = k--;  // q_kk == r
+                const int64_t h = hole[kk - 1];
+                // the hole is below S: no chunk of this pass reads it (its old content was saved in pass 1)
+                put(h, v, rr);
+                if (kk < A) {
+                    const int64_t dst = r - 1;  // q_kk - 1 takes x_{kk+1}
+                    if (dst >= lo) {
+                        put(dst, x_idx[kk], rec ? &x_rec[kk] : nullptr);
+                    } else {
+                        Late& L = late[c];
+                        L.dst = dst;
+                        L.idx = x_idx[kk];
+                        if (rec) L.rec = x_rec[kk];
+                    }
+                }
+            } else if (r == S) {  // the run [S, q_A) rotates: its first element goes to the top of the run
+                Late& L = late[nc];
+                L.dst = (A == 0 ? E : q[A - 1]) - 1;
+                L.idx = v;
+                if (rec) L.rec = *rr;
+            } else if (r - 1 >= lo) {
+                put(r - 1, v, rr);
+            } else {
+                Late& L = late[c];
+                L.dst = r - 1;
+                L.idx = v;
+                if (rec) L.rec = *rr;
+            }
+        }
+    });
+    if (A > 0) {  // x_1 goes to the very top
+        Late& L = late[nc + 1];
+        L.dst = E - 1;
+        L.idx = x_idx[0];
+        if (rec) L.rec = x_rec[0];
+    }
+    for (const Late& L : late)
+        if (L.dst >= 0) put(L.dst, L.idx, &L.rec);
+    return nl;
+}
+
 // Returns the left count, or -1 when the node must become a leaf.  The permutation of idx
 // happens even when the split is then rejected, exactly as in the reference.
 int64_t partition(const Elements& el, int32_t* idx, int64_t first, int64_t count, const Box& parent,
@@ -401,6 +545,14 @@ int64_t partition(const Elements& el, int32_t* idx, int64_t first, int64_t count
     if (!choose_split(el, idx, first, count, parent, cb_known, axis, pos, fallbacks)) return -1;
     int64_t mid = first, end = first + count;
     static const bool fold = std::getenv("RT_NO_FOLD") == nullptr;
+    static const bool par_partition = std::getenv("RT_SERIAL_PARTITION") == nullptr;
+    if (par_partition && count >= kParMin && Pool::get().width() > 1) {
+        const int64_t nl = partition_closed_form(
+            idx, el.rec, first, count, kParChunk, [&](int64_t i) { return elem_cent(el, idx, i)[axis] < pos; },
+            [](int64_t n, const std::function<void(int64_t)>& fn) { Pool::get().parallel_for(n, fn); });
+        if (nl == 0 || nl == count) return -1;
+        return nl;
+    }
     if (fold && sides && count < kParMin) {
         Box lb, rb, lc, rc;
         lb.reset();
@@ -727,6 +879,60 @@ uint32_t leaf_desc(int64_t first, int64_t count, std::vector<uint32_t>& ext) {
 }
 
 }  // namespace
+
+// Test seam: `cases` random class patterns of up to max_n elements (xorshift from `seed`), each partitioned by the
+// reference's serial loop and by partition_closed_form with a random chunk length (so chunk borders fall everywhere,
+// including on S): returns the number of cases whose index permutation, moved records or left count differ.
+int64_t partition_selftest(int64_t cases, uint64_t seed, int max_n) {
+    uint64_t x = seed ? seed : 0x9e3779b97f4a7c15ull;
+    auto rnd = [&]() {
+        x ^= x << 13;
+        x ^= x >> 7;
+        x ^= x << 17;
+        return x;
+    };
+    int64_t bad = 0;
+    std::vector<int32_t> a, b;
+    std::vector<Rec> ra, rb;
+    std::vector<uint8_t> left;
+    const auto serial_run = [](int64_t n, const std::function<void(int64_t)>& fn) {
+        for (int64_t i = 0; i < n; ++i) fn(i);
+    };
+    for (int64_t t = 0; t < cases; ++t) {
+        const int64_t n = 1 + static_cast<int64_t>(rnd() % static_cast<uint64_t>(std::max(1, max_n)));
+        const int64_t first = static_cast<int64_t>(rnd() % 5);
+        const uint64_t bias = rnd() % 11;  // 0: all right-class ... 10: all left-class
+        a.assign(static_cast<size_t>(first + n), -1);
+        ra.assign(static_cast<size_t>(first + n), Rec{});
+        left.assign(static_cast<size_t>(first + n), 0);
+        for (int64_t i = first; i < first + n; ++i) {
+            a[i] = static_cast<int32_t>(i - first);
+            left[i] = (rnd() % 10) < bias;
+            ra[i].c.c[0] = left[i] ? -1.0 : 1.0;  // the class travels with the record
+            ra[i].c.c[1] = static_cast<double>(i - first);
+        }
+        b = a;
+        rb = ra;
+        int64_t mid = first, end = first + n;  // the reference's loop, rtbvh.cpp:271-285
+        while (mid < end) {
+            if (ra[mid].c.c[0] < 0.0) {
+                ++mid;
+            } else {
+                --end;
+                std::swap(a[mid], a[end]);
+                std::swap(ra[mid], ra[end]);
+            }
+        }
+        const int64_t chunk = 1 + static_cast<int64_t>(rnd() % 9);
+        const int64_t nl = partition_closed_form(b.data(), rb.data(), first, n, chunk,
+                                                 [&](int64_t i) { return rb[i].c.c[0] < 0.0; }, serial_run);
+        bool ok = nl == mid - first && a == b;
+        for (int64_t i = first; ok && i < first + n; ++i)
+            ok = ra[i].c.c[1] == rb[i].c.c[1] && ra[i].c.c[0] == rb[i].c.c[0];
+        bad += !ok;
+    }
+    return bad;
+}
 
 Scene* build_scene(int n_meshes, const double* const* coords, const double* const* colors,
                    const int64_t* elem_counts, int timestep, int n_threads) {

@@ -177,3 +177,14 @@ def test_signed_zero_extremes_follow_the_serial_scan_order():
         c[(c == 0.0) & flip] = -0.0
         assert (np.signbit(c) & (c == 0.0)).any() and (~np.signbit(c) & (c == 0.0)).any()
         assert_same_tree([c], [k])
+
+
+def test_parallel_partition_is_the_serial_two_pointer_permutation():
+    """Ranges of >= 65,536 elements are partitioned by a chunk-parallel closed form of the reference's sequential
+    loop (cpp/rtbvh.cpp:271-285; rt_bvh.cpp partition_closed_form).  The permutation must be the loop's own, element for
+    element -- leaves keep this order and ties in t go to the first -- on 10^6 random class patterns with random chunk
+    lengths (all-left, all-right, holes and fillers on chunk borders included), and on longer ranges."""
+    from raytracer_amd import _lib as L
+    assert L.lib.rt_partition_selftest(1_000_000, 12345, 40) == 0
+    assert L.lib.rt_partition_selftest(20_000, 777, 600) == 0
+    assert L.lib.rt_partition_selftest(200, 99, 200_000) == 0
