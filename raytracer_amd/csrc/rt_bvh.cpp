@@ -209,6 +209,10 @@ private:
     bool stop_ = false;
 };
 
+// RT_BUILD_TIMING=1: phase times of every large tree on stderr (tuning aid)
+const bool g_build_timing = std::getenv("RT_BUILD_TIMING") != nullptr;
+inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 constexpr int64_t kTreeParMin = 1 << 13;  // trees over at least this many elements build their subtrees concurrently
 constexpr int64_t kParMin = 1 << 16;    // ranges at least this long are scanned by several threads
 constexpr int64_t kParChunk = 1 << 14;  // elements per chunk of such a scan
@@ -408,18 +412,51 @@ bool no_zero_component(const Box& b) {
 // passes below are chunk-parallel, and the result equals the serial loop's element for element -- which matters:
 // leaves keep their triangles in this order (rtbvh.cpp:515-536) and ties in t go to the first (rtrayintersection.cpp
 // :173-177).  rt_partition_selftest compares the two on random class patterns; tests/test_bvh_build.py on whole trees.
+// `sides` (with `el`): the boxes and centroid bounds of the two sides are gathered in the classification pass, chunk
+// by chunk, and merged in chunk order (see Sides: trusted only without zero components).
 template <class IsLeft, class Run>
 int64_t partition_closed_form(int32_t* idx, Rec* rec, int64_t first, int64_t count, int64_t chunk, const IsLeft& is_left,
-                              const Run& run) {
+                              const Run& run, const Elements* el = nullptr, Sides* sides = nullptr) {
     const int64_t E = first + count, nc = (count + chunk - 1) / chunk;
     std::vector<uint8_t> flag(static_cast<size_t>(count));  // 1 = left-class, by ORIGINAL position
     std::vector<int64_t> cl(static_cast<size_t>(nc)), pa(static_cast<size_t>(nc) + 1, 0), sb(static_cast<size_t>(nc) + 1, 0);
+    struct Four {
+        Box b[4];  // left box, right box, left centroid bounds, right centroid bounds
+    };
+    std::vector<Four> part(sides ? static_cast<size_t>(nc) : 0);
     run(nc, [&](int64_t c) {
         const int64_t lo = first + c * chunk, hi = std::min(E, lo + chunk);
         int64_t n = 0;
-        for (int64_t i = lo; i < hi; ++i) n += (flag[i - first] = is_left(i) ? 1 : 0);
+        if (sides) {
+            Four f;
+            for (Box& b : f.b) b.reset();
+            for (int64_t i = lo; i < hi; ++i) {
+                const int l = is_left(i) ? 1 : 0;
+                flag[i - first] = static_cast<uint8_t>(l);
+                n += l;
+                f.b[1 - l].add_box(elem_box(*el, idx, i));
+                f.b[3 - l].add_point(elem_cent(*el, idx, i));
+            }
+            part[c] = f;
+        } else {
+            for (int64_t i = lo; i < hi; ++i) n += (flag[i - first] = is_left(i) ? 1 : 0);
+        }
         cl[c] = n;
     });
+    if (sides) {
+        Four f;
+        for (Box& b : f.b) b.reset();
+        for (int64_t c = 0; c < nc; ++c)
+            for (int k = 0; k < 4; ++k) f.b[k].add_box(part[c].b[k]);
+        sides->box[0] = f.b[0];
+        sides->box[1] = f.b[1];
+        sides->cent[0] = f.b[2];
+        sides->cent[1] = f.b[3];
+        sides->box_ok[0] = no_zero_component(f.b[0]);
+        sides->box_ok[1] = no_zero_component(f.b[1]);
+        sides->cent_ok[0] = no_zero_component(f.b[2]);
+        sides->cent_ok[1] = no_zero_component(f.b[3]);
+    }
     int64_t nl = 0;
     for (int64_t c = 0; c < nc; ++c) nl += cl[c];
     const int64_t S = first + nl;
@@ -549,7 +586,8 @@ int64_t partition(const Elements& el, int32_t* idx, int64_t first, int64_t count
     if (par_partition && count >= kParMin && Pool::get().width() > 1) {
         const int64_t nl = partition_closed_form(
             idx, el.rec, first, count, kParChunk, [&](int64_t i) { return elem_cent(el, idx, i)[axis] < pos; },
-            [](int64_t n, const std::function<void(int64_t)>& fn) { Pool::get().parallel_for(n, fn); });
+            [](int64_t n, const std::function<void(int64_t)>& fn) { Pool::get().parallel_for(n, fn); }, fold ? &el : nullptr,
+            fold ? sides : nullptr);
         if (nl == 0 || nl == count) return -1;
         return nl;
     }
@@ -708,6 +746,7 @@ void build_tree(std::vector<HostNode>& nodes, const Elements& el, int32_t* idx, 
     // only the node NUMBERS depend on the order the reference's loop pops them in.  So the ranges are partitioned
     // by recursive tasks (the two children of a node concurrently) into a pointer tree, and the loop is then
     // replayed over that tree, serially and without touching an element, to hand out the numbers.
+    const double t_tree0 = now_s();
     std::vector<HostNode> top;
     top.push_back(root);
     std::vector<Deferred> deferred;
@@ -783,6 +822,7 @@ void build_tree(std::vector<HostNode>& nodes, const Elements& el, int32_t* idx, 
         }
     }
 
+    const double t_tree1 = now_s();
     const int64_t nd = static_cast<int64_t>(deferred.size());
     std::vector<std::vector<HostNode>> sub(static_cast<size_t>(nd));
     std::vector<int64_t> sub_fallbacks(static_cast<size_t>(nd), 0);
@@ -795,6 +835,7 @@ void build_tree(std::vector<HostNode>& nodes, const Elements& el, int32_t* idx, 
     });
 
     // splice
+    const double t_tree2 = now_s();
     std::vector<int64_t> block_start(static_cast<size_t>(nd));
     int64_t extra = 0;
     for (int64_t i = 0; i < nd; ++i) {
@@ -835,10 +876,15 @@ void build_tree(std::vector<HostNode>& nodes, const Elements& el, int32_t* idx, 
             nodes[base + static_cast<int64_t>(L)] = n;
         }
     });
+    if (g_build_timing && n_elem >= kParMin)
+        std::fprintf(stderr, "  build_tree %lld elements: top (%zu nodes, %lld deferred) %.1f ms, subtrees %.1f ms, splice %.1f ms\n",
+                     (long long)n_elem, top.size(), (long long)nd, (t_tree1 - t_tree0) * 1e3, (t_tree2 - t_tree1) * 1e3,
+                     (now_s() - t_tree2) * 1e3);
 }
 
 void build_one_blas(HostBlas& b, int32_t mesh, const double* coords_t, int64_t E, Centroid& mesh_cent) {
-    std::vector<Rec> rec(static_cast<size_t>(E));  // boxes + centroids, permuted together with the index array
+    const double t_b0 = now_s();
+    FlatVec<Rec> rec(static_cast<size_t>(E));  // (not zero-filled first) boxes + centroids, permuted together with the index array
     Box mesh_box;
     mesh_box.reset();
     {
@@ -866,7 +912,10 @@ void build_one_blas(HostBlas& b, int32_t mesh, const double* coords_t, int64_t E
     b.sorted_to_elem.resize(static_cast<size_t>(E));
     for (int64_t e = 0; e < E; ++e) b.sorted_to_elem[e] = static_cast<int32_t>(e);
     Elements el{nullptr, nullptr, rec.data()};
+    const double t_b1 = now_s();
     build_tree(b.nodes, el, b.sorted_to_elem.data(), E, 4, b.midpoint_fallbacks);
+    if (g_build_timing && E >= kParMin)
+        std::fprintf(stderr, "  mesh %d: element records %.1f ms, tree %.1f ms\n", mesh, (t_b1 - t_b0) * 1e3, (now_s() - t_b1) * 1e3);
 }
 
 uint32_t leaf_desc(int64_t first, int64_t count, std::vector<uint32_t>& ext) {
@@ -1015,7 +1064,15 @@ Scene* build_scene(int n_meshes, const double* const* coords, const double* cons
         sc->n_blas_nodes += static_cast<int64_t>(sc->slots[s].nodes.size());
     }
     if (node_base > MAX_DEV_NODES) throw std::runtime_error("scene exceeds 2^29 BVH nodes");
-    sc->dev_nodes.assign(static_cast<size_t>(node_base), DevNode{});
+    // (190 MB at 5 M triangles: not filled first -- every node record is written by the sweep below, only the pad
+    // records in front of and behind a slot's nodes are cleared here)
+    sc->dev_nodes.resize(static_cast<size_t>(node_base));
+    for (int s = 0; s < n_slots; ++s) {
+        const int64_t lo = slot_node_base[s], nn = static_cast<int64_t>(sc->slots[s].nodes.size());
+        const int64_t hi = s + 1 < n_slots ? slot_node_base[s + 1] : node_base;
+        sc->dev_nodes[lo] = DevNode{};
+        for (int64_t i = lo + 1 + nn; i < hi; ++i) sc->dev_nodes[i] = DevNode{};
+    }
     sc->tris.resize(static_cast<size_t>(total_tris) * 9);
     sc->colors.resize(static_cast<size_t>(total_tris) * 3);
     sc->prim_mesh.resize(static_cast<size_t>(total_tris));
@@ -1044,28 +1101,39 @@ Scene* build_scene(int n_meshes, const double* const* coords, const double* cons
         const int64_t nb = slot_node_base[s] + 1;
         sc->slot_root[s] = static_cast<int32_t>(nb);
         const int64_t nn = static_cast<int64_t>(b.nodes.size());
-        // children have larger indices than their parent: one reverse sweep gives the stack need
+        // node records: independent of each other, written by several threads
+        {
+            int64_t ncn = 0;
+            for_chunks(0, nn, ncn, [&](int64_t, int64_t lo, int64_t hi) {
+                for (int64_t i = lo; i < hi; ++i) {
+                    const HostNode& h = b.nodes[i];
+                    DevNode& d = sc->dev_nodes[nb + i];
+                    std::memcpy(d.mn, h.mn, sizeof(d.mn));
+                    std::memcpy(d.mx, h.mx, sizeof(d.mx));
+                    if (h.left < 0) {
+                        d.left = -1;
+                        d.count = static_cast<int32_t>(h.count);
+                        d.first = static_cast<int32_t>(tb + h.first);
+                        d.desc = (h.count >= 1 && h.count <= 7)
+                                     ? DESC_LEAF | (static_cast<uint32_t>(h.count - 1) << 28) | static_cast<uint32_t>(tb + h.first)
+                                     : 0u;  // leaf_ext slots are handed out below, in a fixed order
+                    } else {
+                        d.left = static_cast<int32_t>(nb + h.left);
+                        d.count = 0;
+                        d.first = -1;
+                        d.desc = static_cast<uint32_t>(nb + h.left);
+                    }
+                }
+            });
+        }
+        // children have larger indices than their parent: one reverse sweep over the host nodes gives the stack need
         std::vector<int32_t> need(static_cast<size_t>(nn), 0);
         for (int64_t i = nn - 1; i >= 0; --i) {
             const HostNode& h = b.nodes[i];
-            DevNode& d = sc->dev_nodes[nb + i];
-            std::memcpy(d.mn, h.mn, sizeof(d.mn));
-            std::memcpy(d.mx, h.mx, sizeof(d.mx));
             if (h.left < 0) {
-                d.left = -1;
-                d.count = static_cast<int32_t>(h.count);
-                d.first = static_cast<int32_t>(tb + h.first);
-                if (h.count >= 1 && h.count <= 7)
-                    d.desc = DESC_LEAF | (static_cast<uint32_t>(h.count - 1) << 28) | static_cast<uint32_t>(tb + h.first);
-                else
-                    big_leaves[s].push_back(i);  // leaf_ext slots are handed out below, in a fixed order
+                if (!(h.count >= 1 && h.count <= 7)) big_leaves[s].push_back(i);
                 slot_max_leaf[s] = std::max<int32_t>(slot_max_leaf[s], static_cast<int32_t>(h.count));
-                need[i] = 0;
             } else {
-                d.left = static_cast<int32_t>(nb + h.left);
-                d.count = 0;
-                d.first = -1;
-                d.desc = static_cast<uint32_t>(nb + h.left);
                 need[i] = std::max(need[h.left] + 1, need[h.left + 1]);
             }
         }
