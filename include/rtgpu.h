@@ -27,6 +27,7 @@ extern "C" {
 #define RT_E_IO (-4)        /* cannot open output file */
 #define RT_E_LIMIT (-5)     /* scene exceeds an encoding limit */
 #define RT_E_NOMEM (-6)
+#define RT_E_BUSY (-7)      /* rt_render_static: another context's launch still uses this GPU's scratch array */
 
 typedef struct rt_ctx rt_ctx;     /* device context: one per GPU */
 typedef struct rt_scene rt_scene; /* host-side acceleration structure of ONE timestep, flattened */
@@ -39,6 +40,11 @@ int rt_device_count(void);
  * 1..16.  OMP_NUM_THREADS is ignored on purpose (torchrun sets it to 1 for multi-rank jobs).  The reference
  * has one thread; no counterpart. */
 int rt_host_threads(void);
+/* The RT_* tuning / comparison variables are read from the environment once, by the first
+ * rt_create (or the first host-only call that needs one); no render, upload or driver call reads the environment.
+ * This re-reads them -- for tests and benchmarks that switch a variable between two calls of one process.  Call it
+ * only while no other call of this library is in flight.  No counterpart in the reference (it has no knobs). */
+int rt_reload_options(void);
 /* Page-locked host memory for rt_download targets (hipHostMalloc): device-to-host copies into pageable memory
  * run at ~10 GB/s, into pinned memory at the link's rate.  NULL on failure.  No counterpart in the reference
  * (its frame never leaves the host). */
@@ -170,14 +176,18 @@ int rt_render(rt_ctx *ctx, const rt_render_params *params);
 /* ------------------------------------------------------------------ */
 /* rt_render for callers that CANNOT ALLOCATE.  No counterpart in the   */
 /* reference (which allocates per leaf visit); it exists for callers    */
-/* that must not reach hipMalloc: code under HIP graph capture, tight   */
-/* serving loops, harnesses that forbid allocation.                     */
+/* that must not reach hipMalloc: tight serving loops, harnesses that   */
+/* forbid allocation, processes close to the device-memory limit.       */
+/* (NOT capturable in a HIP graph: the call waits for this context's    */
+/* previous launch, reads event times and launches on the context's     */
+/* own stream.)                                                         */
 /* Same kernels and results as rt_render (packet path), but nothing is  */
 /* allocated or freed: the camera-relative node / TLAS / triangle       */
-/* records the prep kernels write and the visit counters live in a      */
-/* file-scope device array of RT_STATIC_SCRATCH_BYTES that every GPU    */
-/* the library runs on holds until the process ends; jitter and outputs */
-/* are the CALLER's device memory:                                      */
+/* records the prep kernels write, the pixel blocks' cuts when they fit */
+/* behind them, and the visit counters live in a file-scope device      */
+/* array of RT_STATIC_SCRATCH_BYTES that every GPU the library runs on  */
+/* holds until the process ends; jitter and outputs are the CALLER's    */
+/* device memory:                                                       */
 /*   d_jitter   : (row_end-row_begin)*W*spp (ox,oy) pairs, order (j,i,k) */
 /*   d_intensity: rows*W f64     d_rgb: rows*W*3 u8                     */
 /*   d_hit_prim : rows*W*spp i32, required with RT_FLAG_HIT_IDS else NULL */
@@ -187,12 +197,16 @@ int rt_render(rt_ctx *ctx, const rt_render_params *params);
 /* sizes in rt_last_error): 256 + 64*n_tlas + 64*n_dev_nodes +          */
 /* 128*n_tris bytes (each part rounded up to 256) must fit the array    */
 /* (about 400,000 triangles), and the tree must fit the packet kernel   */
-/* (stack_need <= 128).  The launch is asynchronous on the context's    */
-/* stream: rt_sync() before reading the outputs; rt_last_stats reports  */
-/* its kernel time and counters.  The MT19937 stream position and the   */
-/* outputs held for rt_download are untouched.  All calls on one GPU    */
-/* share that GPU's array: calls that overlap on one GPU (two contexts, */
-/* two threads) race -- serialise them.                                 */
+/* (stack_need <= 128).  The call returns when its kernels are          */
+/* enqueued on the context's stream (after waiting for the context's    */
+/* PREVIOUS launch): rt_sync() before reading the outputs;              */
+/* rt_last_stats reports its kernel time, counters and whether cuts     */
+/* were used (finest_cut_level).  The MT19937 stream position and the   */
+/* outputs held for rt_download are untouched.  All contexts on one GPU */
+/* share that GPU's array: a call made while ANOTHER context's launch   */
+/* into it has not finished returns RT_E_BUSY and launches nothing      */
+/* (calls are serialised by a per-process lock; processes sharing a GPU */
+/* have an array each).                                                 */
 /* ------------------------------------------------------------------ */
 #define RT_STATIC_SCRATCH_BYTES (64u << 20)
 int rt_render_static(rt_ctx *ctx, const rt_render_params *params, const double *d_jitter, double *d_intensity,
@@ -221,15 +235,21 @@ typedef struct {
     double render_kernel_ms_total;
     uint64_t render_launches_timed;
     uint64_t jitter_streams; /* MT19937 sampler: streams the launch's offsets were generated on (0: other samplers) */
+    int64_t finest_cut_level; /* packet kernels: level (log2 of the block side in pixels) of the finest cuts the launch's
+                                 walk started from, -1 when it walked from the TLAS root (test seam, see rt_last_cuts) */
 } rt_stats;
 int rt_last_stats(const rt_ctx *ctx, rt_stats *out);
 int rt_sync(rt_ctx *ctx);
 
-/* Test seams for the cuts (DESIGN.md 4.2 "cuts"; no counterpart in the reference, whose walk always starts at node
- * 0, cpp/rtrayintersection.cpp:203).  Per block of (1 << level)^2 pixels 32 words: header (bit31 valid, bits 13..8
- * the three axis kinds, bits 7..0 entry count) and up to 31 entries in visit order at which the walk of that
- * block's rays starts instead of at the TLAS root.  Blocks are numbered row-major, *tiles_x per row; levels
- * *level_lo .. *level_top exist (the top one is a single block).
+/* Test seams for the cuts (no counterpart in the reference, whose walk always starts at node 0,
+ * cpp/rtrayintersection.cpp:203).  Per block of (1 << level)^2 pixels 32 words: a header -- bit 31 valid, bit 16
+ * CUT_SIMPLE (the list holds only leaf descriptors and trimmed-leaf pairs), bits 13..8 the three axis kinds, bits 7..0
+ * the entry count -- and up to 31 entries in visit order at which the walk of that block's rays starts instead of at
+ * the TLAS root: a plain descriptor (every ray of the block passes the node), CUT_NODE | index (BLAS node tested per
+ * ray; with CUT_TRIM, finest level only, followed by the descriptor of the leaf's live triangle range) or
+ * DESC_TLAS | index (TLAS node tested per ray).  Blocks are numbered row-major, *tiles_x per row; levels
+ * *level_lo .. *level_top exist, the top one being max(render tile, 8 x 8 pixels) -- many blocks, each refined from
+ * the TLAS root -- not a single block for the image.
  * rt_last_cuts: those of the last rt_render, from the device.  Returns the number of blocks of `level` (0 when
  * the last render made no cuts), or a negative error; words = NULL only queries.
  * rt_tile_cuts_host: host-only twin (the same code compiled for the host) for this scene, camera and image (only

@@ -20,6 +20,7 @@ RT_FLAG_COUNTERS = 2
 RT_FLAG_HIT_T = 4
 RT_FLAG_FP32 = 8
 RT_STATIC_SCRATCH_BYTES = 64 << 20
+RT_E_BUSY = -7
 
 
 class RtError(RuntimeError):
@@ -44,7 +45,7 @@ class Stats(C.Structure):
                 ("rays", C.c_uint64), ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64),
                 ("rays_hit", C.c_uint64), ("wave_node_fetches", C.c_uint64), ("wave_tri_fetches", C.c_uint64),
                 ("render_kernel_ms_total", C.c_double), ("render_launches_timed", C.c_uint64),
-                ("jitter_streams", C.c_uint64)]
+                ("jitter_streams", C.c_uint64), ("finest_cut_level", C.c_int64)]
 
 
 # name -> (restype, argtypes).  Every symbol declared in include/rtgpu.h is listed here;
@@ -55,6 +56,7 @@ _PROTOS = {
     "rt_version": (C.c_char_p, []),
     "rt_device_count": (C.c_int, []),
     "rt_host_threads": (C.c_int, []),
+    "rt_reload_options": (C.c_int, []),
     "rt_partition_selftest": (C.c_int64, [C.c_int64, C.c_uint64, C.c_int]),
     "rt_host_alloc": (_VP, [C.c_size_t]),
     "rt_host_free": (None, [_VP]),
@@ -112,7 +114,35 @@ def _load():
     return lib
 
 
-lib = _load()
+class _Lib:
+    """The loaded library.  librtgpu.so takes its RT_* options from the environment once (rt_create) and again only on
+    rt_reload_options(); scripts and tests written against this package switch such variables between two calls of one
+    process (os.environ[...] = ...), so every call through this object first re-reads them when any RT_* variable has
+    changed since the last call -- one comparison of a small tuple per call."""
+
+    def __init__(self, raw):
+        self._raw = raw
+        self._seen = None
+
+    def _sync(self):
+        now = tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("RT_")))
+        if now != self._seen:
+            self._raw.rt_reload_options()
+            self._seen = now
+
+    def __getattr__(self, name):
+        fn = getattr(self._raw, name)
+        if name in ("rt_last_error", "rt_reload_options"):
+            call = fn
+        else:
+            def call(*args, _fn=fn):
+                self._sync()
+                return _fn(*args)
+        self.__dict__[name] = call
+        return call
+
+
+lib = _Lib(_load())
 
 
 def check(rc, what=""):

@@ -224,7 +224,14 @@ class Context:
     def download(self, intensity=True, rgb=True, hit_ids=None, hit_t=None, pinned=True):
         """Results of the last render as numpy arrays (in page-locked memory unless pinned=False)."""
         rows, W, spp = self._shape
-        empty = pinned_empty if pinned else (lambda shape, dtype=np.float64: np.empty(shape, dtype))
+        def empty(shape, dtype=np.float64):
+            if pinned:
+                try:
+                    return pinned_empty(shape, dtype)
+                except L.RtError:  # no page-locked memory left (per-sample outputs can be several GB): pageable copy
+                    pass
+            return np.empty(shape, dtype)
+
         hit_ids = bool(self._flags & L.RT_FLAG_HIT_IDS) if hit_ids is None else hit_ids
         hit_t = bool(self._flags & L.RT_FLAG_HIT_T) if hit_t is None else hit_t
         out = {}

@@ -50,6 +50,40 @@ int fail(int code, const std::string& msg) {
             return fail(RT_E_NO_DEVICE, std::string(#expr) + " failed: " + hipGetErrorString(e_)); \
     } while (0)
 
+
+// ---- options -----------------------------------------------------------------------------------------------
+// Every RT_* tuning / comparison / test variable of this file is read from the environment ONCE
+// -- by the first rt_create, or by the first host-only call that needs one -- and again only on rt_reload_options():
+// no render, upload or driver call reaches getenv.  opt("RT_X") returns the value taken then, or null when unset,
+// so each site keeps the meaning it had when it asked the environment itself.
+const char* const kOptionNames[] = {"RT_ADAPT_MIN_WORDS", "RT_ADAPT_RATIO", "RT_BUILD_AHEAD", "RT_BUILD_TIMING", "RT_COUNT_WITH_CUTS", "RT_CUT_LO", "RT_CUT_MIN_RAYS", "RT_CUT_STEP", "RT_CUT_TOP", "RT_CUT_TOPCAP", "RT_DRIVER_TIMING", "RT_FORCE_PERLANE", "RT_INTERLEAVE", "RT_JITTER_SLOT_BYTES", "RT_JITTER_STREAMS", "RT_NO_ADAPT_STREAMS", "RT_NO_CUT", "RT_NO_FRAME_GROUPS", "RT_NO_INTERLEAVE", "RT_NO_LOOKAHEAD", "RT_NO_PAIR64", "RT_NO_PIPELINE", "RT_NO_PREP_OVERLAP", "RT_NO_SMALL_TILES", "RT_NO_STATE_REUSE", "RT_NO_TRIM", "RT_PAD64_FROM", "RT_RNG_PRIO", "RT_STAGE_STREAMS", "RT_TILE_LOG2"};
+constexpr int kNumOptions = (int)(sizeof(kOptionNames) / sizeof(kOptionNames[0]));
+struct OptionTable {
+    std::mutex mu;
+    bool loaded = false;
+    bool set[kNumOptions] = {};
+    std::string val[kNumOptions];
+    void load() {  // (callers hold mu)
+        for (int i = 0; i < kNumOptions; ++i) {
+            const char* e = std::getenv(kOptionNames[i]);
+            set[i] = e != nullptr;
+            val[i] = e ? e : "";
+        }
+        loaded = true;
+    }
+} g_options;
+
+// Not safe against a concurrent rt_reload_options (documented: reload while no call is in flight).
+const char* opt(const char* name) {
+    if (!g_options.loaded) {
+        std::lock_guard<std::mutex> lk(g_options.mu);
+        if (!g_options.loaded) g_options.load();
+    }
+    for (int i = 0; i < kNumOptions; ++i)
+        if (std::strcmp(kOptionNames[i], name) == 0) return g_options.set[i] ? g_options.val[i].c_str() : nullptr;
+    return nullptr;  // (not a registered option: a typo in this file)
+}
+
 double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -92,7 +126,7 @@ struct CutPlan {
 // Entries a list of level l may hold: coarse levels only hand a starting point down (their blocks are refined
 // again, four times over, by their children), so they stop at half the room.
 int cut_cap(int l, const CutPlan& cp) {
-    const int top_cap = std::getenv("RT_CUT_TOPCAP") ? std::atoi(std::getenv("RT_CUT_TOPCAP")) : 15;  // (tuning knob)
+    const int top_cap = opt("RT_CUT_TOPCAP") ? std::atoi(opt("RT_CUT_TOPCAP")) : 15;  // (tuning knob)
     return (l > cp.lo + 1) ? std::max(1, std::min(top_cap, (int)rtk::CUT_CAP)) : (int)rtk::CUT_CAP;
 }
 
@@ -104,20 +138,22 @@ CutPlan plan_cuts(int W, int rows, int spp, int tile_log2) {
     // ... but not below 2 x 2 pixels: measured on the 4096^2 x 64 spp frame, per-pixel cuts take 0.7 ms off the
     // render kernel and cost 3 ms to make
     cp.lo = std::max(cp.lo, 1);
-    if (const char* e = std::getenv("RT_CUT_LO")) cp.lo = std::max(0, std::atoi(e));  // (tuning knob)
+    if (const char* e = opt("RT_CUT_LO")) cp.lo = std::max(0, std::atoi(e));  // (tuning knob)
     cp.lo = std::min(cp.lo, tile_log2);
     // The top level's blocks start at the TLAS root, one thread each: a long chain of dependent steps, but the
     // same for any number of blocks, so the hierarchy starts where there are enough blocks to fill the GPU with
     // that chain (8 x 8 pixels or the render tile), not at the single block that holds the image.
     cp.top = std::max(tile_log2, 3);
-    if (const char* e = std::getenv("RT_CUT_TOP")) cp.top = std::max(cp.lo, std::atoi(e));  // (tuning knob)
+    // (tuning knob; never below the render tile's level: a batch looks its cut up at levels lo..tile_log2 and takes
+    // the next coarser level that was made, which must exist)
+    if (const char* e = opt("RT_CUT_TOP")) cp.top = std::max({cp.lo, tile_log2, std::atoi(e)});
     int whole = 0;
     while ((1 << whole) < std::max(W, rows)) ++whole;
     cp.top = std::max(cp.lo, std::min(cp.top, std::max(whole, tile_log2)));
     // every level: a batch that straddles two blocks of the finest level takes the next coarser level's cut, and the
     // further up that is, the looser (2048^2 x 50 spp, two pixels per batch: 6.21 -> 5.87 ms per frame against
     // every second level; one pixel per batch at 64 spp: no difference)
-    const int step = std::getenv("RT_CUT_STEP") ? std::max(1, std::atoi(std::getenv("RT_CUT_STEP"))) : 1;  // (tuning knob)
+    const int step = opt("RT_CUT_STEP") ? std::max(1, std::atoi(opt("RT_CUT_STEP"))) : 1;  // (tuning knob)
     for (int l = cp.top; l >= cp.lo; --l) {
         // every `step`-th level below the top, and the finest one
         if (l != cp.lo && (cp.top - l) % step != 0) continue;
@@ -259,6 +295,7 @@ struct rt_ctx {
     DevBuf<int32_t> frame_hit_prim;
     unsigned long long* stats_counters = nullptr;  // where the last launch's visit counters are (or null)
     unsigned char* static_scratch = nullptr;       // this GPU's copy of the file-scope `scratch` (rt_render_static)
+    hipEvent_t static_done = nullptr;              // recorded behind every rt_render_static launch (created in rt_create)
     DevBuf<uint32_t> gstack;
     int32_t out_rows = 0, out_w = 0, out_spp = 0;
     uint32_t out_flags = 0;
@@ -319,7 +356,7 @@ void launch_render(int stack, dim3 grid, hipStream_t st, const rtk::RenderArgs& 
 }
 
 bool force_per_lane() {
-    const char* e = std::getenv("RT_FORCE_PERLANE");
+    const char* e = opt("RT_FORCE_PERLANE");
     return e && e[0] == '1';
 }
 
@@ -342,7 +379,7 @@ struct StreamPlan {
 
 // Frames from this many words on learn the stream count of their look-ahead fills (adapt_streams).
 uint64_t adapt_min_words() {
-    const char* e = std::getenv("RT_ADAPT_MIN_WORDS");  // (test knob: the suites' frames are far smaller)
+    const char* e = opt("RT_ADAPT_MIN_WORDS");  // (test knob: the suites' frames are far smaller)
     return e ? (uint64_t)std::max(0.0, std::atof(e)) : (uint64_t(1) << 30);
 }
 
@@ -366,7 +403,7 @@ StreamPlan plan_streams(int rows, int W, int spp, int frames = 1, int hidden_n =
     // (adapt_streams below): the sampler's workgroups hold wave slots the traversal kernel would use, so it should
     // run on as few as still finish well before the traversal it hides behind
     if (hidden_n > 0 && words >= adapt_min_words()) target = (uint64_t)hidden_n;
-    if (const char* e = std::getenv("RT_JITTER_STREAMS")) target = (uint64_t)std::max(1, std::atoi(e));
+    if (const char* e = opt("RT_JITTER_STREAMS")) target = (uint64_t)std::max(1, std::atoi(e));
     uint64_t stride = (words + target - 1) / target;
     stride = (stride + 623) / 624 * 624;
     p.n = (int)((words + stride - 1) / stride);
@@ -486,7 +523,7 @@ int fill_slot(rt_ctx* c, int k, uint64_t ahead, int rows, int W, int spp, int fr
     const uint64_t new_pos = c->pos + ahead;
     sl.states_ok = false;
     if (ot.states_ok && ot.states_n == pl.n && ot.states_stride == pl.stride && new_pos > ot.states_pos &&
-        !std::getenv("RT_NO_STATE_REUSE")) {  // (tuning knob)
+        !opt("RT_NO_STATE_REUSE")) {  // (tuning knob)
         const unsigned long long* poly = nullptr;
         if ((rc = dev_poly(c, new_pos - ot.states_pos, &poly))) return rc;
         HIP_TRY(hipMemsetAsync(sl.d_states.p, 0, size_t(pl.n) * sizeof(rt::MtState), c->rng_stream));
@@ -579,7 +616,7 @@ int stage_scene(rt_ctx* c, const rt::Scene& s) {
     st->used = false;
     const double t_copy0 = now_ms();
     if (copy_scene_to(st->b, s, st->stream) != RT_OK) return give_up();
-    if (std::getenv("RT_BUILD_TIMING"))
+    if (opt("RT_BUILD_TIMING"))
         std::fprintf(stderr, "stage_scene: %.1f MB copied to the device in %.2f ms\n",
                      (s.dev_nodes.size() * sizeof(rt::DevNode) + s.tris.size() * 8 + s.colors.size() * 8) / 1e6,
                      now_ms() - t_copy0);
@@ -617,7 +654,7 @@ int ensure_staged_pool(rt_ctx* c, size_t n) {
         std::unique_ptr<rt_ctx::StagedSet> st(new rt_ctx::StagedSet());
         // RT_STAGE_STREAMS=1: one stream per set; default: the first NSTAGE_STREAMS sets' streams are shared by the
         // rest -- the number of HIP streams of a context then does not grow with RT_BUILD_AHEAD
-        const size_t n_own = std::getenv("RT_STAGE_STREAMS") ? ~size_t(0) : size_t(1);
+        const size_t n_own = opt("RT_STAGE_STREAMS") ? ~size_t(0) : size_t(1);
         if (c->staged.size() < n_own) {
             HIP_TRY(hipStreamCreateWithFlags(&st->stream, hipStreamNonBlocking));
             st->owns_stream = true;
@@ -637,6 +674,9 @@ rt_ctx* g_global_ctx[64] = {};
 constexpr int kMaxDevices = 64;
 std::mutex g_scratch_mu;
 unsigned char* g_scratch_ptr[kMaxDevices] = {};
+// Who launched last into each GPU's scratch array (rt_render_static): a call from ANOTHER context while that launch
+// has not finished would overwrite the records its kernels are reading -- it is refused with RT_E_BUSY instead.
+rt_ctx* g_scratch_owner[kMaxDevices] = {};
 
 // Resolve (once per device, with that device current) the address of this device's copy of `scratch`.
 int static_scratch_ptr(int device, unsigned char** out) {
@@ -661,6 +701,11 @@ const char* rt_last_error(void) { return g_err.c_str(); }
 const char* rt_version(void) { return "rtgpu 0.1 (gfx950, fp64 parity path)"; }
 
 int rt_host_threads(void) { return rt::host_threads(); }
+int rt_reload_options(void) {
+    std::lock_guard<std::mutex> lk(g_options.mu);
+    g_options.load();
+    return RT_OK;
+}
 int64_t rt_partition_selftest(int64_t cases, uint64_t seed, int max_n) {
     try {
         return rt::partition_selftest(cases, seed, max_n);
@@ -851,7 +896,7 @@ rt_ctx* rt_create(int device) {
         g_err = "rt_create: copy stream / events";
         return nullptr;
     }
-    const char* pe = std::getenv("RT_RNG_PRIO");  // tuning knob: "lo" = same priority as the traversal stream
+    const char* pe = opt("RT_RNG_PRIO");  // tuning knob: "lo" = same priority as the traversal stream
     const int prio_rng = (pe && pe[0] == 'l') ? prio_lo : prio_hi;
     if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_lo) != hipSuccess ||
         hipStreamCreateWithPriority(&c->rng_stream, hipStreamNonBlocking, prio_rng) != hipSuccess) {
@@ -891,6 +936,11 @@ rt_ctx* rt_create(int device) {
     if (c->d_state.ensure(rt::MT_N) != RT_OK) return nullptr;
     // rt_render_static must not call anything that could allocate: its scratch address is resolved here
     if (static_scratch_ptr(device, &c->static_scratch) != RT_OK) return nullptr;
+    if (hipEventCreateWithFlags(&c->static_done, hipEventDisableTiming) != hipSuccess) {
+        g_err = "rt_create: event for the static scratch array";
+        return nullptr;
+    }
+    (void)opt("RT_NO_CUT");  // the RT_* options are taken from the environment here, once (see OptionTable)
     rt_ctx* raw = c.release();
     if (rt_rng_seed(raw, 5489u) != RT_OK) {
         rt_destroy(raw);
@@ -903,6 +953,11 @@ void rt_destroy(rt_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    {
+        std::lock_guard<std::mutex> lk(g_scratch_mu);
+        if (c->device >= 0 && c->device < kMaxDevices && g_scratch_owner[c->device] == c) g_scratch_owner[c->device] = nullptr;
+    }
+    if (c->static_done) (void)hipEventDestroy(c->static_done);
     if (c->rng_stream) (void)hipStreamSynchronize(c->rng_stream);
     c->nodes.release();
     c->tlas.release();
@@ -1114,12 +1169,12 @@ namespace {
 // are fewer than 8192 tiles and a wave (a quarter of the tile) still has >= 128 rays to walk.
 int pick_tile_log2(bool packet_like, int spp, int W, int rows) {
     int tile_log2 = (spp >= 4) ? 3 : 4;
-    static const bool small_tiles = std::getenv("RT_NO_SMALL_TILES") == nullptr;
+    const bool small_tiles = opt("RT_NO_SMALL_TILES") == nullptr;
     if (small_tiles && packet_like)
         while (tile_log2 > 1 && int64_t((W + (1 << tile_log2) - 1) >> tile_log2) * ((rows + (1 << tile_log2) - 1) >> tile_log2) < 8192 &&
                (int64_t(1) << (2 * (tile_log2 - 1) - 2)) * spp >= 128)
             --tile_log2;
-    if (const char* e = std::getenv("RT_TILE_LOG2")) {  // tuning knob (packet kernels: 1..4, per-lane kernel: 3 or 4)
+    if (const char* e = opt("RT_TILE_LOG2")) {  // tuning knob (packet kernels: 1..4, per-lane kernel: 3 or 4)
         const int v = std::atoi(e);
         if (v >= (packet_like ? 1 : 3) && v <= 4) tile_log2 = v;
     }
@@ -1181,11 +1236,11 @@ int make_cuts(rt_ctx* c, hipStream_t st, const rt_render_params* p, int tile_log
               bool allowed, CutTables& out) {
     out = CutTables{};
     const int W = p->image_width, spp = p->samples, rows = p->row_end - p->row_begin;
-    const bool no_cut = std::getenv("RT_NO_CUT") != nullptr;  // (comparison / test knob, read per launch)
+    const bool no_cut = opt("RT_NO_CUT") != nullptr;  // (comparison / test knob, read per launch)
     // The cut kernels are chains of dependent steps (~0.3 ms however small the image) and save a third to a half of
     // the traversal.  Measured: 2048^2 x 4 spp (16.7 M rays, 1 M triangles) 1.47 -> 1.32 ms per frame with cuts,
     // 400 x 225 x 50 spp (4.5 M rays) 0.30 -> 0.49 ms.
-    const char* mr = std::getenv("RT_CUT_MIN_RAYS");  // (tuning knob)
+    const char* mr = opt("RT_CUT_MIN_RAYS");  // (tuning knob)
     const double min_rays = mr ? std::atof(mr) : 12e6;
     if (!cuts || !allowed || no_cut || double(rows) * W * spp < min_rays) return RT_OK;
     const CutPlan cp = plan_cuts(W, rows, spp, tile_log2);
@@ -1211,7 +1266,7 @@ int make_cuts(rt_ctx* c, hipStream_t st, const rt_render_params* p, int tile_log
         ca.n_tiles = (int32_t)cp.tiles[l];
         ca.cuts = cuts + cp.offset_words[l];
         // the finest level's leaves lose the triangles no ray of the block can hit (cut_trim); RT_NO_TRIM: comparison knob
-        ca.tris = (l == cp.lo && !std::getenv("RT_NO_TRIM")) ? cam_tris : nullptr;
+        ca.tris = (l == cp.lo && !opt("RT_NO_TRIM")) ? cam_tris : nullptr;
         const int64_t patches = int64_t((cp.tiles_x[l] + 7) / 8) * ((cp.tiles[l] / cp.tiles_x[l] + 7) / 8);
         const int per_wg = rtk::CUT_THREADS / 64;  // one 8 x 8 patch of blocks per wave
         hipLaunchKernelGGL(rtk::cut_level_kernel, dim3((unsigned)((patches + per_wg - 1) / per_wg)), dim3(rtk::CUT_THREADS),
@@ -1223,7 +1278,7 @@ int make_cuts(rt_ctx* c, hipStream_t st, const rt_render_params* p, int tile_log
     // what a batch finds at level l: that level's cuts, or those of the next coarser level that was made
     for (int l = cp.lo; l <= tile_log2 && l < rtk::CUT_MAX_LEVELS; ++l) {
         int e = l;
-        while (!cp.present[e]) ++e;  // the top level (>= tile_log2) always is
+        while (e < cp.top && !cp.present[e]) ++e;  // the top level (>= tile_log2) always is
         out.lvl[l] = cuts + cp.offset_words[e];
         out.tx[l] = cp.tiles_x[e];
         out.eff[l] = e;
@@ -1257,7 +1312,7 @@ int launch_packet_prep(rt_ctx* c, hipStream_t st, const rt_render_params* p, int
     pp.fast_ok = (c->max_abs_coord + std::fabs(ox) + std::fabs(oy) + std::fabs(oz)) < 1e100 ? 2 : 0;
     // (visit counters count the reference's visit rule, so a counting launch walks from the root; RT_COUNT_WITH_CUTS=1
     // counts what the cut walk really fetches and tests instead -- profiling aid)
-    const bool count_cuts = std::getenv("RT_COUNT_WITH_CUTS") != nullptr;
+    const bool count_cuts = opt("RT_COUNT_WITH_CUTS") != nullptr;
     return make_cuts(c, st, p, tile_log2, pp.fpv, pb.cam_nodes, pb.cam_tlas, pb.cam_tris, pb.cuts,
                      (!count || count_cuts) && pp.fast_ok == 2, pp.ct);
 }
@@ -1292,14 +1347,14 @@ int launch_packet_kernel(rt_ctx* c, const rt_render_params* p, int tile_log2, in
     // (an even number of batches per wave: 16 or 4 pixels per wave, or one pixel of >= 128 samples)
     if (spp >= 64 && (spp & (spp - 1)) == 0 && (tile_log2 == 3 || tile_log2 == 2 || (tile_log2 == 1 && spp >= 128)) &&
         c->stack_need <= rtk::PAIR64_STACK &&
-        !std::getenv("RT_NO_PAIR64"))
+        !opt("RT_NO_PAIR64"))
         for (int q = spp >> 6; q; q >>= 1) ++a.pair64;
     // Sample counts a little below 64 * 2^n (from 49/64 of it): the same instantiation with the last lanes idle beats
     // batches that straddle pixels (their cuts are those of bigger blocks, and their index arithmetic is per lane):
     // 2048^2, 1 M triangles, 50 spp 5.85 -> 5.21 ms, 56 spp 5.99 -> 5.29, 63 spp 7.01 -> 5.40; 48 spp 5.08 -> 5.17 and
     // 40 spp 4.57 -> 5.05 stay generic
-    static const int pad_from = std::getenv("RT_PAD64_FROM") ? std::atoi(std::getenv("RT_PAD64_FROM")) : 49;  // (tuning knob, per 64)
-    if (a.pair64 == 0 && spp > 32 && c->stack_need <= rtk::PAIR64_STACK && !std::getenv("RT_NO_PAIR64")) {
+    const int pad_from = opt("RT_PAD64_FROM") ? std::atoi(opt("RT_PAD64_FROM")) : 49;  // (tuning knob, per 64)
+    if (a.pair64 == 0 && spp > 32 && c->stack_need <= rtk::PAIR64_STACK && !opt("RT_NO_PAIR64")) {
         int padded = 64, lg = 0;
         while (padded < spp) {
             padded <<= 1;
@@ -1311,8 +1366,8 @@ int launch_packet_kernel(rt_ctx* c, const rt_render_params* p, int tile_log2, in
             (tile_log2 == 3 || tile_log2 == 2 || (tile_log2 == 1 && padded >= 128)))
             a.pair64 = 1 + lg;
     }
-    a.interleave = std::getenv("RT_NO_INTERLEAVE") ? 0 : (a.pair64 ? 1 : 0);
-    if (const char* e = std::getenv("RT_INTERLEAVE")) a.interleave = std::atoi(e);  // experiment: 0, 1, 2, 4, ...
+    a.interleave = opt("RT_NO_INTERLEAVE") ? 0 : (a.pair64 ? 1 : 0);
+    if (const char* e = opt("RT_INTERLEAVE")) a.interleave = std::atoi(e);  // experiment: 0, 1, 2, 4, ...
     if (a.interleave && ((a.interleave & (a.interleave - 1)) || a.interleave > ((1 << (2 * tile_log2)) >> 2))) a.interleave = 0;
     a.fast_ok = pp.fast_ok;
     for (int l = 0; l < rtk::CUT_MAX_LEVELS; ++l) {
@@ -1321,6 +1376,7 @@ int launch_packet_kernel(rt_ctx* c, const rt_render_params* p, int tile_log2, in
         a.cut_eff[l] = pp.ct.eff[l];
     }
     a.cut_lo = pp.ct.lo;
+    c->stats.finest_cut_level = a.cut_lo;  // (test seam: -1 = this launch walks from the root)
     if (cuts_made) *cuts_made = a.cut_lo >= 0;
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     if (count && a.pair64)
@@ -1348,7 +1404,7 @@ int launch_packet(rt_ctx* c, const rt_render_params* p, int tile_log2, int tiles
 // Called when the previous launch is known to be complete (its kernel time resolved): learn the stream count of
 // the look-ahead fills of very large frames from that launch's sampler and traversal times (see rt_ctx::adapt_n).
 void adapt_streams(rt_ctx* c, int rows, int W, int spp) {
-    if (std::getenv("RT_NO_ADAPT_STREAMS") || std::getenv("RT_JITTER_STREAMS")) return;  // (tuning knobs)
+    if (opt("RT_NO_ADAPT_STREAMS") || opt("RT_JITTER_STREAMS")) return;  // (tuning knobs)
     if (!c->kernel_ms_known || !c->jitter_timed || c->out_rows != rows || c->out_w != W || c->out_spp != spp) return;
     if (uint64_t(rows) * uint64_t(W) * uint64_t(spp) * 4u < adapt_min_words()) return;
     const rt_ctx::JitterSlot& sl = c->slot[c->last_slot];  // the slot that launch read: its fill is complete
@@ -1360,7 +1416,7 @@ void adapt_streams(rt_ctx* c, int rows, int W, int spp) {
     }
     const double render_ms = c->stats.render_kernel_ms;
     if (!(sampler_ms > 0.f) || !(render_ms > 0.0)) return;
-    const char* re = std::getenv("RT_ADAPT_RATIO");  // (test knob)
+    const char* re = opt("RT_ADAPT_RATIO");  // (test knob)
     // (0.95, was 0.8: the sampler's workgroups hold wave slots and its jumps are work, so the fewer streams the
     // better as long as the fill still ends before the traversal it hides behind -- 4096^2 x 64: 21.0 -> 20.5 ms per
     // step, same box; rounding up to a multiple of 64 streams is the margin)
@@ -1438,7 +1494,7 @@ int render_impl(rt_ctx* c, const rt_render_params* p, bool pipelined) {
     rt_ctx::CamSet* cs = nullptr;
     CutPlan cp;
     // (small frames of small scenes: the two cross-stream dependencies cost more than the ~10 us of prep they hide)
-    const bool overlap = std::getenv("RT_NO_PREP_OVERLAP") == nullptr &&  // (comparison knob, read per launch)
+    const bool overlap = opt("RT_NO_PREP_OVERLAP") == nullptr &&  // (comparison knob, read per launch)
                          (n_smp >= (size_t(1) << 24) || c->n_tris >= (1 << 18));
     if (packet_launch) {
         c->cam_idx ^= 1;
@@ -1624,8 +1680,8 @@ int render_impl(rt_ctx* c, const rt_render_params* p, bool pipelined) {
         a.tile_log2 = tile_log2;
         a.tiles_x = tiles_x;
         a.n_tiles = (int32_t)n_tiles;
-        a.pair64 = (spp == 64 && (tile_log2 == 3 || tile_log2 == 2) && c->stack_need <= rtk::PAIR64_STACK && !std::getenv("RT_NO_PAIR64")) ? 1 : 0;
-        a.interleave = (std::getenv("RT_NO_INTERLEAVE") || !a.pair64) ? 0 : 1;
+        a.pair64 = (spp == 64 && (tile_log2 == 3 || tile_log2 == 2) && c->stack_need <= rtk::PAIR64_STACK && !opt("RT_NO_PAIR64")) ? 1 : 0;
+        a.interleave = (opt("RT_NO_INTERLEAVE") || !a.pair64) ? 0 : 1;
         a.jitter = d_jitter;
         a.intensity = c->intensity.p;
         a.rgb = c->rgb.p;
@@ -1708,7 +1764,7 @@ int render_impl(rt_ctx* c, const rt_render_params* p, bool pipelined) {
     // ---- look-ahead: while the GPU traverses, generate the jitter of the predicted next call
     // (same shape; same distance between starts as the last two calls, else contiguous) into the
     // other slot.  A wrong guess costs nothing but the wasted work.
-    if (p->sampler == RT_SAMPLER_MT19937 && !std::getenv("RT_NO_LOOKAHEAD")) {
+    if (p->sampler == RT_SAMPLER_MT19937 && !opt("RT_NO_LOOKAHEAD")) {
         try {
             const uint64_t fw = uint64_t(n_smp) * 4u;
             uint64_t next = c->pos;
@@ -1720,7 +1776,7 @@ int render_impl(rt_ctx* c, const rt_render_params* p, bool pipelined) {
             // group instead of per frame -- the jumps alone take as long as such a frame's traversal), and the group
             // after the one in use is generated while the first of its frames renders.
             int group = 1;
-            if (next == c->pos && !std::getenv("RT_NO_FRAME_GROUPS"))
+            if (next == c->pos && !opt("RT_NO_FRAME_GROUPS"))
                 group = (int)std::max<uint64_t>(1, std::min<uint64_t>(16, (uint64_t(1) << 25) / std::max<size_t>(n_smp, 1)));
             const rt_ctx::JitterSlot& cur_sl = c->slot[use];
             uint64_t target = next;
@@ -1753,7 +1809,7 @@ int band_rows_for(const rt_render_params* p) {
     const int W = p->image_width, spp = p->samples, rows = p->row_end - p->row_begin;
     if (W < 1 || spp < 1 || rows < 16) return 0;
     double budget = 32.0 * 1024.0 * 1024.0 * 1024.0;
-    if (const char* e = std::getenv("RT_JITTER_SLOT_BYTES")) budget = std::max(1.0, std::atof(e));
+    if (const char* e = opt("RT_JITTER_SLOT_BYTES")) budget = std::max(1.0, std::atof(e));
     const double row_bytes = double(W) * spp * 16.0;
     if (double(rows) * row_bytes <= budget) return 0;
     const int64_t fit = (int64_t)(budget / row_bytes);
@@ -1889,6 +1945,19 @@ int rt_render_static(rt_ctx* c, const rt_render_params* p, const double* d_jitte
     if (!ptr) return fail(RT_E_NO_DEVICE, "rt_render_static: scratch address not resolved");
     const int rows = p->row_end - p->row_begin;
     HIP_TRY(hipSetDevice(c->device));
+    // One array per GPU, shared by every context on it.  The lock is held until this call's launches and its
+    // `static_done` event are enqueued, so two threads cannot interleave their launches; a launch of ANOTHER context
+    // that has not finished yet still reads the array: refuse instead of overwriting what it reads.
+    std::lock_guard<std::mutex> scratch_lock(g_scratch_mu);
+    if (rt_ctx* owner = g_scratch_owner[c->device]) {
+        if (owner != c) {
+            const hipError_t q = hipEventQuery(owner->static_done);
+            if (q == hipErrorNotReady)
+                return fail(RT_E_BUSY, "rt_render_static: another context's launch is still using this GPU's scratch array "
+                                       "(rt_sync that context first, or serialise the callers)");
+            if (q != hipSuccess) return fail(RT_E_NO_DEVICE, std::string("rt_render_static: hipEventQuery: ") + hipGetErrorString(q));
+        }
+    }
     // the previous launch of this context may still be reading the scratch records
     HIP_TRY(hipStreamSynchronize(c->stream));
     int rc = resolve_kernel_ms(c);
@@ -1922,7 +1991,10 @@ int rt_render_static(rt_ctx* c, const rt_render_params* p, const double* d_jitte
                size_t(RT_STATIC_SCRATCH_BYTES))
                   ? reinterpret_cast<uint32_t*>(ptr + off_cuts)
                   : nullptr;
-    if ((rc = launch_packet(c, p, tile_log2, tiles_x, n_tiles, pb))) return rc;
+    g_scratch_owner[c->device] = c;  // (before the launch: even a launch that fails half-way may have enqueued kernels)
+    rc = launch_packet(c, p, tile_log2, tiles_x, n_tiles, pb);
+    HIP_TRY(hipEventRecord(c->static_done, c->stream));
+    if (rc) return rc;
     HIP_TRY(hipEventRecord(c->front_last_use, c->stream));  // rt_upload_scene waits for it before reusing the set
     c->front_used = true;
     c->timing_pending = true;
@@ -2052,7 +2124,7 @@ int rt_tile_cuts_host(const rt_scene* scene, const rt_render_params* p, int leve
         ca.tiles_x = cp.tiles_x[l];
         ca.n_tiles = (int32_t)cp.tiles[l];
         ca.cuts = cur.data();
-        ca.tris = (l == cp.lo && !std::getenv("RT_NO_TRIM")) ? tris.data() : nullptr;
+        ca.tris = (l == cp.lo && !opt("RT_NO_TRIM")) ? tris.data() : nullptr;
         for (int64_t t = 0; t < cp.tiles[l]; ++t) {
             rtk::cut_refine(ca, (int)t, lists, 1);
             if (ca.tris) rtk::cut_trim(ca, (int)t, lists, 1);
@@ -2248,7 +2320,7 @@ int rt_render_scene(int image_height, int image_width, int number_of_samples, co
         });
     };
     // RT_DRIVER_TIMING=1: per-phase wall time of this call on stderr (tuning aid)
-    const bool timing = std::getenv("RT_DRIVER_TIMING") != nullptr;
+    const bool timing = opt("RT_DRIVER_TIMING") != nullptr;
     double t_wait = 0, t_upload = 0, t_render = 0, t_down = 0, t_write = 0;
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     // Builds run ahead of the GPU on helper threads: up to `depth` timesteps in flight (each build is
@@ -2256,7 +2328,7 @@ int rt_render_scene(int image_height, int image_width, int number_of_samples, co
     int64_t tris_per_step = 0;
     for (int m = 0; m < n_meshes; ++m) tris_per_step += elem_counts[m];
     size_t depth = tris_per_step > 4000000 ? 1 : (tris_per_step > 500000 ? 2 : 3);
-    if (const char* e = std::getenv("RT_BUILD_AHEAD")) depth = (size_t)std::max(1, std::atoi(e));
+    if (const char* e = opt("RT_BUILD_AHEAD")) depth = (size_t)std::max(1, std::atoi(e));
     std::deque<std::future<Built>> pending;
     size_t next_step = 0;
     auto top_up = [&]() {
@@ -2278,7 +2350,7 @@ int rt_render_scene(int image_height, int image_width, int number_of_samples, co
     std::vector<uint8_t> rgb2[2] = {std::vector<uint8_t>(rgb_bytes), std::vector<uint8_t>(rgb_bytes)};
     std::future<void> writer;
     int wbuf = 0;
-    bool pipeline = std::getenv("RT_NO_PIPELINE") == nullptr;  // (tuning knob)
+    bool pipeline = opt("RT_NO_PIPELINE") == nullptr;  // (tuning knob)
     {  // frames rendered band by band (render_frame) end with a wait and swap whole-frame buffers in: not pipelined
         rt_render_params probe;
         std::memset(&probe, 0, sizeof(probe));
@@ -2291,6 +2363,7 @@ int rt_render_scene(int image_height, int image_width, int number_of_samples, co
     }
     bool have_prev = false;
     int prev_t = 0, prev_cam = 0;
+    int64_t pending_sah_lines = 0;
     top_up();
     int built_t = -1;
     for (int64_t q = 0; q < n_mine; ++q) {
@@ -2313,8 +2386,10 @@ int rt_render_scene(int image_height, int image_width, int number_of_samples, co
                 bail(0);
                 return fail(RT_E_INVALID, msg);
             }
-            for (int64_t k = 0; k < b.sc->s->midpoint_fallbacks; ++k)
-                std::printf("SAH splitting failed. Trying midpoint instead.\n");  // cpp/rtbvh.cpp:128
+            // cpp/rtbvh.cpp:128 prints one line per fallback while the timestep's trees are built, i.e. before the
+            // timestep's first "Rendering frame": this build ran ahead on a helper thread, so the lines are held back
+            // until that frame is announced
+            pending_sah_lines += b.sc->s->midpoint_fallbacks;
             t0 = now();
             int urc = RT_OK;
             if (b.staged >= 0)
@@ -2329,6 +2404,8 @@ int rt_render_scene(int image_height, int image_width, int number_of_samples, co
         };
         if (t != built_t && (rc = advance_scene(t))) return rc;
         if ((rc = rt_rng_seek(c, my_pos[q]))) return bail(rc);
+        for (; pending_sah_lines > 0; --pending_sah_lines)
+            std::printf("SAH splitting failed. Trying midpoint instead.\n");  // cpp/rtbvh.cpp:128
         std::printf("Rendering frame %d/%d\n", t + 1, timestep_count);  // cpp/rtmain.cpp:61
         std::fflush(stdout);
         rt_render_params p;

@@ -33,7 +33,7 @@ def test_struct_layouts_match_header_sizes():
     # sizes computed from the header's field lists (natural alignment)
     assert C.sizeof(L.RenderParams) == 12 * 8 + 7 * 4 + 4 + 8
     assert C.sizeof(L.SceneInfo) == 4 + 4 + 8 * 3 + 4 + 4 + 8 + 8
-    assert C.sizeof(L.Stats) == 3 * 8 + 6 * 8 + 8 + 8 + 8
+    assert C.sizeof(L.Stats) == 3 * 8 + 6 * 8 + 8 + 8 + 8 + 8
 
 
 def test_version_and_errors():
