@@ -20,6 +20,7 @@ Prints ONE JSON line on rank 0.  Besides the contract's fields it carries, under
 tolerance, and for N > 1 one frame split into row bands over the ranks (strong scaling) with its gather.
 """
 import argparse
+import socket
 import json
 import os
 import sys
@@ -218,9 +219,12 @@ def bench_multiframe(ra, rank, world, local_rank, dist, steps_per_rank=16):
     run(min(T, 2 * world))  # warm-up: polynomials, allocations
     if dist is not None:
         dist.barrier()
+    cpu0 = time.process_time()  # CPU time of this process, all threads (build pool, helpers, file writer, HIP waits)
     t0 = time.perf_counter()
     run(T)
     elapsed = time.perf_counter() - t0
+    cpu_s = time.process_time() - cpu0
+    my_steps = len(set(int(f) // 2 for f in ra.shard_frames(T, 2, rank, world)[0]))
     if dist is not None:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64, device=TDEV)
@@ -231,7 +235,17 @@ def bench_multiframe(ra, rank, world, local_rank, dist, steps_per_rank=16):
         os.remove(os.path.join(out_dir, f))
     os.rmdir(out_dir)
     frames = T * 2
+    threads = int(L.lib.rt_host_threads())
+    cpu_ms_step = cpu_s / max(1, my_steps) * 1e3
     return {"frames_per_s": frames / elapsed, "frames": frames, "seconds": elapsed, "image": [H, W], "spp": spp,
+            # what the HOST can supply: this rank spent cpu_ms_per_timestep of CPU time per timestep it rendered (tree
+            # builds, staging, read-back waits, P6 files) and has `host_threads` cores of its own, so however fast the
+            # GPU is it cannot render more than host_threads / cpu time per timestep -- per rank; x world for the job
+            "cpu_ms_per_timestep": cpu_ms_step,
+            "host_bound_ceiling": {"host_threads_per_rank": threads,
+                                   "frames_per_s_per_rank": threads / (cpu_ms_step * 1e-3) * 2 if cpu_ms_step > 0 else None,
+                                   "frames_per_s_job": world * threads / (cpu_ms_step * 1e-3) * 2 if cpu_ms_step > 0 else None,
+                                   "note": "cores of this rank / CPU time per timestep x 2 cameras (rank 0's figures)"},
             "meshes": 8, "triangles": int(counts.sum()), "cameras": 2, "timesteps": T,
             "mrays_per_s": frames * H * W * spp / elapsed / 1e6, "files_written_by_rank0": n_files,
             "includes": "per-timestep host BVH build (overlapped), upload, render, read-back, P6 write"}
@@ -243,18 +257,49 @@ def rehearse(rank, world, local_rank):
     import torch.distributed as dist
     import raytracer_amd as ra
     from raytracer_amd import _lib as L
+    if "RANK" not in os.environ:  # --gpus 1 without a launcher: a world of one
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo")
     H, W, spp, T, n_cam = 4096, 4096, 64, 100, 2
     frames, pos = ra.shard_frames(T, n_cam, rank, world, 0, H * W * spp * 4)
     mine = {"rank": rank, "local_rank": local_rank, "host_threads": int(L.lib.rt_host_threads()),
             "omp_num_threads_env": os.environ.get("OMP_NUM_THREADS"), "frames": [int(f) for f in frames],
             "band": list(ra.shard_rows(H, W, spp, rank, world, 0))[:2]}
+    # what this node's HOST can supply to `world` ranks: every rank builds the multi-frame driver's timestep scene
+    # (8 meshes x 32,768 triangles, rebuilt per timestep) on its own share of the cores, all ranks at once -- no GPU.
+    if os.environ.get("RT_REHEARSE_BUILDS", "1") != "0":
+        from raytracer_amd import meshgen
+        coords, colors = [], []
+        for m in range(8):
+            c, k = meshgen.plate(128, side=5.0, x0=-10.0 + 5.0 * (m % 4), y0=-5.0 + 5.0 * (m // 4), z0=-6.0)
+            coords.append(np.ascontiguousarray(c))
+            colors.append(np.ascontiguousarray(k))
+        ra.HostScene(coords, colors, 0).close()  # warm-up: the pool's threads
+        dist.barrier()
+        n_builds = 12
+        cpu0, t0 = time.process_time(), time.perf_counter()
+        for _ in range(n_builds):
+            ra.HostScene(coords, colors, 0).close()
+        wall, cpu = time.perf_counter() - t0, time.process_time() - cpu0
+        mine["build"] = {"timesteps_per_s": n_builds / wall, "wall_ms_per_timestep": wall / n_builds * 1e3,
+                         "cpu_ms_per_timestep": cpu / n_builds * 1e3}
     everyone = [None] * world
     dist.all_gather_object(everyone, mine)
     dist.barrier()
     dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps({"rehearsal": True, "n_gpus": world, "ranks": everyone}))
+        out = {"rehearsal": True, "n_gpus": world, "ranks": everyone}
+        if all("build" in r for r in everyone):
+            tps = sum(r["build"]["timesteps_per_s"] for r in everyone)
+            out["host_build_supply"] = {
+                "scene": "8 meshes x 32,768 triangles per timestep (bench_multiframe's)", "cores_visible": len(os.sched_getaffinity(0)),
+                "timesteps_per_s_all_ranks": tps, "frames_per_s_ceiling_2_cameras": 2 * tps,
+                "note": "tree builds only (no staging, read-back, files): an upper bound on the job's frames/s that no "
+                        "number of GPUs lifts; compare across --gpus 1/2/4/8 on the same host"}
+        print(json.dumps(out))
 
 
 def main():

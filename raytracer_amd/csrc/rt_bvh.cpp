@@ -109,7 +109,7 @@ inline const double* elem_cent(const Elements& el, const int32_t* idx, int64_t i
 // cores this process may run on (sched_getaffinity) divided among the ranks of this node (LOCAL_WORLD_SIZE,
 // set by torchrun), 1..16.  OMP_NUM_THREADS is deliberately NOT consulted: torchrun exports OMP_NUM_THREADS=1
 // to multi-rank jobs, and a rank that built its trees on one thread would be host-bound (hard part 3).
-int host_threads() {
+static int host_threads_uncached() {
     if (const char* e = std::getenv("RT_HOST_THREADS")) {
         const int n = std::atoi(e);
         if (n > 0) return std::min(n, 64);
@@ -123,7 +123,35 @@ int host_threads() {
     if (const char* e = std::getenv("LOCAL_WORLD_SIZE")) ranks = std::max(1, std::atoi(e));
     return std::max(1, std::min(cores / ranks, 16));
 }
+int host_threads() {  // (read once: the pool is sized by the first call)
+    static const int n = host_threads_uncached();
+    return n;
+}
 namespace {
+
+// One process per GPU (torchrun): LOCAL_WORLD_SIZE ranks share this node's cores, and each rank's build pool has
+// cores / ranks threads (host_threads).  Left to the scheduler, the pools of eight ranks wander over the same cores;
+// so rank LOCAL_RANK's workers are bound to the LOCAL_RANK-th of LOCAL_WORLD_SIZE equal spans of the CPUs this process
+// may run on (the first `threads` CPUs of the span).  Only when the ranks evidently share one CPU set: more than one
+// rank, LOCAL_RANK given, and room for every rank's threads.  RT_NO_PIN=1 leaves the threads unbound.  Empty: no pinning.
+std::vector<int> rank_cpu_slice(int threads) {
+    std::vector<int> out;
+    const char* lw = std::getenv("LOCAL_WORLD_SIZE");
+    const char* lr = std::getenv("LOCAL_RANK");
+    if (!lw || !lr || std::getenv("RT_NO_PIN")) return out;
+    const int ranks = std::atoi(lw), rank = std::atoi(lr);
+    if (ranks < 2 || rank < 0 || rank >= ranks || threads < 1) return out;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof(set), &set) != 0) return out;
+    std::vector<int> allowed;
+    for (int c = 0; c < CPU_SETSIZE; ++c)
+        if (CPU_ISSET(c, &set)) allowed.push_back(c);
+    const int span = static_cast<int>(allowed.size()) / ranks;
+    if (span < threads) return out;
+    for (int i = 0; i < threads; ++i) out.push_back(allowed[static_cast<size_t>(rank * span + i)]);
+    return out;
+}
 
 class Pool {
 public:
@@ -179,8 +207,15 @@ private:
         }
     }
     explicit Pool(int n) {
+        const std::vector<int> cpus = rank_cpu_slice(n + 1);
         for (int i = 0; i < n; ++i)
-            workers_.emplace_back([this] {
+            workers_.emplace_back([this, cpus] {
+                if (!cpus.empty()) {  // several ranks on this node: this rank's workers keep to its own cores
+                    cpu_set_t set;
+                    CPU_ZERO(&set);
+                    for (int c : cpus) CPU_SET(c, &set);
+                    (void)sched_setaffinity(0, sizeof(set), &set);
+                }
                 for (;;) {
                     std::shared_ptr<Job> job;
                     {
