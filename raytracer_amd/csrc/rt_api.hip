@@ -1376,6 +1376,7 @@ int launch_packet_kernel(rt_ctx* c, const rt_render_params* p, int tile_log2, in
         a.cut_eff[l] = pp.ct.eff[l];
     }
     a.cut_lo = pp.ct.lo;
+    a.spp_magic = 65536u / (uint32_t)std::max(spp, 1) + 1u;
     c->stats.finest_cut_level = a.cut_lo;  // (test seam: -1 = this launch walks from the root)
     if (cuts_made) *cuts_made = a.cut_lo >= 0;
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));

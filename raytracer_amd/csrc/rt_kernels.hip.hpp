@@ -899,6 +899,9 @@ struct PacketArgs {
     int32_t cut_tx[5];
     int32_t cut_eff[5];  // level whose cuts cut_lvl[l] / cut_tx[l] are: l, or the next coarser one that was made
     int32_t cut_lo;
+    // generic instantiation: floor(r / spp) for 0 <= r < spp + 128 without a division -- spp >= 64: r >= spp (0 or 1);
+    // else (r * spp_magic) >> 16 with spp_magic = 65536 / spp + 1 (exact while r * spp < 65536)
+    uint32_t spp_magic;
 };
 
 // blockIdx -> tile.  `tile` already gives XCD x (blocks b == x mod 8) a contiguous run of tiles.  When the
@@ -1491,7 +1494,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 8), amdgp
     };
     int vzero;
     asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
-    auto fetch = [&](const int base) {
+    // generic instantiation: the ray index base + lane is split into (pixel, sample) without a per-lane division:
+    // qb = base / spp and rb = base % spp are wave-uniform and advance by (64 / spp, 64 % spp) per batch
+    const uint32_t magic = a.spp_magic;
+    auto div_spp = [&](const int r) -> int {  // floor(r / spp), 0 <= r < spp + 128
+        return spp >= 64 ? (r >= spp ? 1 : 0) : (int)(((uint32_t)r * magic) >> 16);
+    };
+    const int q64 = P64 ? 0 : 64 / spp, r64 = P64 ? 0 : 64 - q64 * spp;
+    auto fetch = [&](const int base, const int qb, const int rb) {
         Slot q;
         const int rr = base + lane;
         // P64: wave-uniform (RT_P64_VZERO: carried in a VGPR all the same, by adding an opaque zero, so that the
@@ -1510,8 +1520,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 8), amdgp
             lgq = p64v - 1;
         }
         const int sppq = P64 ? (64 << lgq) : spp;
-        const int ml = P64 ? (base >> (6 + lgq)) + (RT_P64_VZERO ? vzero : 0) : rr / spp;
-        const int k = P64 ? (base & (sppq - 1)) + lane : rr - ml * spp;
+        const int dq = P64 ? 0 : div_spp(rb + lane);
+        const int ml = P64 ? (base >> (6 + lgq)) + (RT_P64_VZERO ? vzero : 0) : qb + dq;
+        const int k = P64 ? (base & (sppq - 1)) + lane : rb + lane - dq * spp;
         const int m = wave_pixel(ml, wv, m0, ilv);
         q.px = tx0 + (int)compact1by1((uint32_t)m);
         q.py = ty0 + (int)compact1by1((uint32_t)m >> 1);
@@ -1571,10 +1582,20 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 8), amdgp
         }
         return q;
     };
-    Slot nxt = fetch(0);
+    int qn = 0, rn = 0;  // (base + 64) / spp and % spp of the batch being fetched
+    Slot nxt = fetch(0, 0, 0);
     for (int base = 0; base < n_rays; base += 64) {
         const Slot cs = nxt;
-        if (base + 64 < n_rays) nxt = fetch(base + 64);
+        const int qc = qn, rc = rn;  // base / spp, base % spp
+        if (!P64) {
+            qn += q64;
+            rn += r64;
+            if (rn >= spp) {
+                rn -= spp;
+                ++qn;
+            }
+        }
+        if (base + 64 < n_rays) nxt = fetch(base + 64, qn, rn);
         const int px = cs.px, py = cs.py;
         const bool active = cs.active;
         const size_t sidx = cs.sidx;
@@ -1789,8 +1810,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 8), amdgp
         __builtin_amdgcn_wave_barrier();
         {
             const int end = min(base + 64, n_rays);
-            const int m_first = base / spp;
-            const int m_last = (end - 1) / spp;
+            const int m_first = qc;                                    // base / spp
+            const int m_last = qc + div_spp(rc + (end - 1 - base));   // (end - 1) / spp
             const int work = (m_last - m_first + 1) * 3;
             for (int q = lane; q < work; q += 64) {
                 const int pm = m_first + q / 3;
