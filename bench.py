@@ -178,7 +178,7 @@ def cpu_baseline(coords, colors, cam, H, W, spp, ctx_check, host, budget_rays):
                                    rows_checked=len(rows)) if ctx_check is not None else None)
 
 
-def bench_multiframe(ra, rank, world, local_rank, dist, steps_per_rank=16):
+def bench_multiframe(ra, rank, world, local_rank, dist, steps_per_rank=48):
     """frames/s of rt_render_scene on a displacement sequence: 8 meshes x 32,768 triangles, 2 cameras,
     1024x576, 50 spp, `steps_per_rank * world` timesteps (each rank renders its share of the frames)."""
     import ctypes as C

@@ -9,4 +9,6 @@ import raytracer_amd as ra  # noqa: E402
 
 for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 4):
     r = bench.bench_multiframe(ra, 0, 1, 0, None)
-    print("%.0f frames/s (%d frames in %.1f ms)" % (r["frames_per_s"], r["frames"], r["seconds"] * 1e3), flush=True)
+    print("%.0f frames/s (%d frames in %.1f ms), CPU %.1f ms per timestep, host-bound ceiling %.0f frames/s" % (
+        r["frames_per_s"], r["frames"], r["seconds"] * 1e3, r["cpu_ms_per_timestep"],
+        r["host_bound_ceiling"]["frames_per_s_per_rank"]), flush=True)

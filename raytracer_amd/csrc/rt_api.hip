@@ -56,7 +56,7 @@ int fail(int code, const std::string& msg) {
 // -- by the first rt_create, or by the first host-only call that needs one -- and again only on rt_reload_options():
 // no render, upload or driver call reaches getenv.  opt("RT_X") returns the value taken then, or null when unset,
 // so each site keeps the meaning it had when it asked the environment itself.
-const char* const kOptionNames[] = {"RT_ADAPT_MIN_WORDS", "RT_ADAPT_RATIO", "RT_BUILD_AHEAD", "RT_BUILD_TIMING", "RT_COUNT_WITH_CUTS", "RT_CUT_LO", "RT_CUT_MIN_RAYS", "RT_CUT_STEP", "RT_CUT_TOP", "RT_CUT_TOPCAP", "RT_DRIVER_TIMING", "RT_FORCE_PERLANE", "RT_INTERLEAVE", "RT_JITTER_SLOT_BYTES", "RT_JITTER_STREAMS", "RT_NO_ADAPT_STREAMS", "RT_NO_CUT", "RT_NO_FRAME_GROUPS", "RT_NO_INTERLEAVE", "RT_NO_LOOKAHEAD", "RT_NO_PAIR64", "RT_NO_PIPELINE", "RT_NO_PREP_OVERLAP", "RT_NO_SMALL_TILES", "RT_NO_STATE_REUSE", "RT_NO_TRIM", "RT_PAD64_FROM", "RT_RNG_PRIO", "RT_STAGE_STREAMS", "RT_TILE_LOG2"};
+const char* const kOptionNames[] = {"RT_ADAPT_MIN_WORDS", "RT_ADAPT_RATIO", "RT_BUILD_AHEAD", "RT_BUILD_TIMING", "RT_COUNT_WITH_CUTS", "RT_CUT_LO", "RT_CUT_MIN_RAYS", "RT_CUT_STEP", "RT_CUT_TOP", "RT_CUT_TOPCAP", "RT_DRIVER_TIMING", "RT_FORCE_PERLANE", "RT_INTERLEAVE", "RT_JITTER_SLOT_BYTES", "RT_JITTER_STREAMS", "RT_NO_ADAPT_STREAMS", "RT_NO_CUT", "RT_NO_FRAME_GROUPS", "RT_NO_INTERLEAVE", "RT_NO_LOOKAHEAD", "RT_NO_PAIR64", "RT_NO_PIPELINE", "RT_NO_PREP_OVERLAP", "RT_NO_SERIAL_TREES", "RT_NO_SMALL_TILES", "RT_NO_STATE_REUSE", "RT_NO_TRIM", "RT_PAD64_FROM", "RT_RNG_PRIO", "RT_STAGE_STREAMS", "RT_TILE_LOG2"};
 constexpr int kNumOptions = (int)(sizeof(kOptionNames) / sizeof(kOptionNames[0]));
 struct OptionTable {
     std::mutex mu;
@@ -2309,12 +2309,27 @@ int rt_render_scene(int image_height, int image_width, int number_of_samples, co
         int staged = -1;  // index of the device buffer set the helper thread filled, or -1
         std::string err;
     };
+    // Builds run ahead of the GPU on helper threads: up to `depth` timesteps in flight (each build is
+    // itself parallel over meshes), fewer for big scenes whose flattened copies are large.
+    int64_t tris_per_step = 0;
+    for (int m = 0; m < n_meshes; ++m) tris_per_step += elem_counts[m];
+    size_t depth = tris_per_step > 4000000 ? 1 : (tris_per_step > 500000 ? 2 : 4);
+    if (const char* e = opt("RT_BUILD_AHEAD")) depth = (size_t)std::max(1, std::atoi(e));
+    // enough meshes in flight to occupy every core: one thread per tree (least CPU time per timestep, see rt_bvh.cpp)
+    const bool serial_trees = int64_t(n_meshes) * int64_t(depth) >= int64_t(rt::host_threads()) && !opt("RT_NO_SERIAL_TREES");
     auto build_async = [&](int t) {
         return std::async(std::launch::async, [=]() {
             Built b;
-            b.sc = rt_scene_build(n_meshes, coords, colors, elem_counts, t, 0);
-            if (!b.sc)
-                b.err = rt_last_error();  // thread-local message of the helper thread
+            try {
+                std::unique_ptr<rt_scene> h(new rt_scene());
+                h->s.reset(rt::build_scene(n_meshes, coords, colors, elem_counts, t, 0, serial_trees));
+                b.sc = h.release();
+            } catch (const std::exception& e) {
+                b.err = std::string("rt_scene_build: ") + e.what();
+            }
+            if (!b.sc) {
+                if (b.err.empty()) b.err = "rt_scene_build failed";
+            }
             else
                 b.staged = stage_scene(c, *b.sc->s);
             return b;
@@ -2324,12 +2339,6 @@ int rt_render_scene(int image_height, int image_width, int number_of_samples, co
     const bool timing = opt("RT_DRIVER_TIMING") != nullptr;
     double t_wait = 0, t_upload = 0, t_render = 0, t_down = 0, t_write = 0;
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    // Builds run ahead of the GPU on helper threads: up to `depth` timesteps in flight (each build is
-    // itself parallel over meshes), fewer for big scenes whose flattened copies are large.
-    int64_t tris_per_step = 0;
-    for (int m = 0; m < n_meshes; ++m) tris_per_step += elem_counts[m];
-    size_t depth = tris_per_step > 4000000 ? 1 : (tris_per_step > 500000 ? 2 : 3);
-    if (const char* e = opt("RT_BUILD_AHEAD")) depth = (size_t)std::max(1, std::atoi(e));
     std::deque<std::future<Built>> pending;
     size_t next_step = 0;
     auto top_up = [&]() {

@@ -248,7 +248,13 @@ private:
 const bool g_build_timing = std::getenv("RT_BUILD_TIMING") != nullptr;
 inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-constexpr int64_t kTreeParMin = 1 << 13;  // trees over at least this many elements build their subtrees concurrently
+// build_scene(..., serial_trees = true): every mesh's tree is built by ONE thread (the reference's own loop, the least
+// CPU time per tree).  The whole-job driver asks for it when the meshes of the timesteps it keeps in flight already
+// outnumber the cores: parallelism then comes from the meshes, and the 40 % of CPU time the task-split build spends on
+// hand-overs goes into more timesteps per second instead (8 x 32,768 triangles: 72 -> 51 ms of CPU time per timestep).
+thread_local bool tl_serial_trees = false;
+// trees over at least this many elements build their subtrees concurrently (RT_TREE_PAR_MIN: tuning knob, read once)
+const int64_t kTreeParMin = std::getenv("RT_TREE_PAR_MIN") ? std::atoll(std::getenv("RT_TREE_PAR_MIN")) : (1 << 13);
 constexpr int64_t kParMin = 1 << 16;    // ranges at least this long are scanned by several threads
 constexpr int64_t kParChunk = 1 << 14;  // elements per chunk of such a scan
 
@@ -771,7 +777,7 @@ void build_tree(std::vector<HostNode>& nodes, const Elements& el, int32_t* idx, 
     root.first = 0;
     // (from 8 K elements on: the multi-frame driver rebuilds meshes of a few 10 K triangles per timestep, and a
     // build that only runs one thread per mesh leaves half of a 16-core host idle with 8 meshes)
-    if (n_elem < kTreeParMin || Pool::get().width() == 1) {
+    if (n_elem < kTreeParMin || Pool::get().width() == 1 || tl_serial_trees) {
         nodes.reserve(static_cast<size_t>(n_elem) * 2 / std::max(1, max_leaf - 1) + 8);
         nodes.push_back(root);
         expand(nodes, el, idx, max_leaf, fallbacks, 0, nullptr);
@@ -1019,7 +1025,7 @@ int64_t partition_selftest(int64_t cases, uint64_t seed, int max_n) {
 }
 
 Scene* build_scene(int n_meshes, const double* const* coords, const double* const* colors,
-                   const int64_t* elem_counts, int timestep, int n_threads) {
+                   const int64_t* elem_counts, int timestep, int n_threads, bool serial_trees) {
     const auto t_start = std::chrono::steady_clock::now();
     if (n_meshes < 1) throw std::runtime_error("scene needs at least one mesh");
     if (timestep < 0) throw std::runtime_error("negative timestep");
@@ -1040,6 +1046,7 @@ Scene* build_scene(int n_meshes, const double* const* coords, const double* cons
 
     // ---- BLAS per mesh (independent; built concurrently, results do not depend on threads) ----
     auto work = [&](int m) {
+        tl_serial_trees = serial_trees;  // (thread-local: this mesh's worker)
         const int64_t E = elem_counts[m];
         build_one_blas(blases[m], m, coords[m] + static_cast<int64_t>(timestep) * E * 9, E, mesh_cent[m]);
     };

@@ -110,6 +110,6 @@ struct Scene {
 // test seam (rt_partition_selftest): mismatches between the serial two-pointer partition and its parallel closed form
 int64_t partition_selftest(int64_t cases, uint64_t seed, int max_n);
 Scene* build_scene(int n_meshes, const double* const* coords, const double* const* colors,
-                   const int64_t* elem_counts, int timestep, int n_threads);
+                   const int64_t* elem_counts, int timestep, int n_threads, bool serial_trees = false);
 
 }  // namespace rt
