@@ -45,6 +45,8 @@ int rt_host_threads(void);
  * This re-reads them -- for tests and benchmarks that switch a variable between two calls of one process.  Call it
  * only while no other call of this library is in flight.  No counterpart in the reference (it has no knobs). */
 int rt_reload_options(void);
+/* The names of those variables, comma-separated (static storage). */
+const char *rt_option_names(void);
 /* Page-locked host memory for rt_download targets (hipHostMalloc): device-to-host copies into pageable memory
  * run at ~10 GB/s, into pinned memory at the link's rate.  NULL on failure.  No counterpart in the reference
  * (its frame never leaves the host). */

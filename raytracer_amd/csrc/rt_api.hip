@@ -701,6 +701,14 @@ const char* rt_last_error(void) { return g_err.c_str(); }
 const char* rt_version(void) { return "rtgpu 0.1 (gfx950, fp64 parity path)"; }
 
 int rt_host_threads(void) { return rt::host_threads(); }
+const char* rt_option_names(void) {
+    static const std::string joined = [] {
+        std::string j;
+        for (int i = 0; i < kNumOptions; ++i) j += std::string(i ? "," : "") + kOptionNames[i];
+        return j;
+    }();
+    return joined.c_str();
+}
 int rt_reload_options(void) {
     std::lock_guard<std::mutex> lk(g_options.mu);
     g_options.load();
