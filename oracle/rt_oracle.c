@@ -13,19 +13,29 @@
  * this library, and only as the checker.  The product (raytracer_amd/) never
  * links, imports or calls it.
  *
- * PARITY STATUS: "parity unpinned" against the compiled reference.  The
- * reference's hot-path .cpp files include <nanobind/...> (cpp/rtbvh.h:11-14,
- * cpp/rtrender.h:9-12) and nanobind is absent from this image, so the
- * reference is unbuildable here and no stand-in headers are written.  What IS
- * pinned (tests/test_oracle_pins.py):
+ * PARITY STATUS: the reference's hot-path .cpp files include <nanobind/...>
+ * (cpp/rtbvh.h:11-14, cpp/rtrender.h:9-12) and nanobind is absent from this
+ * image, so the reference is unbuildable here and no stand-in headers are
+ * written; the reference holds no test or golden vector for this path.  What
+ * pins this file instead (DESIGN.md section 6 has the table):
  *   - orc_rng_* against the reference's own header cpp/rtmathutils.h compiled
  *     from the mount (oracle/eigen_probe.cpp -> oracle/_ref/, golden vectors in
- *     tests/golden/) and against this image's libstdc++;
+ *     tests/golden/) and against MT19937's published known answer;
  *   - the floating-point evaluation order of every Eigen expression on the path
  *     (normalized(), rowwise().sum(), cwise products, minCoeff, 1/array) against
  *     the reference's vendored Eigen headers evaluated on the same expression
- *     shapes (oracle/eigen_probe.cpp);
- *   - the camera golden values recorded in SURVEY.md section 8(c).
+ *     shapes (oracle/eigen_probe.cpp), tests/test_oracle_pins.py;
+ *   - the camera golden values recorded in SURVEY.md section 8(c);
+ *   - the builder's branches, the TLAS slot quirk and the walk's tie rules against
+ *     hand-derivable fixtures (oracle/derive_tree_fixtures.py, a line-by-line third
+ *     statement evaluated in binary64 and in exact rationals; derivation in
+ *     tests/golden/tree_fixtures_derivation.txt), tests/test_tree_fixtures.py;
+ *   - the walk's hit ids against orc_brute_force below -- every triangle tested
+ *     with the pinned Moller-Trumbore row, no tree -- tests/test_treeless.py;
+ *   - the survey's visit statistics of the compiled reference (43.9 / 4.39 / 0.906).
+ * Still unpinned: builder decisions that hinge on a rounding on large irregular
+ * trees, and whole images against a file of the reference (it ships none that can
+ * be regenerated).
  *
  * All arithmetic is IEEE binary64, round-to-nearest-even, no FMA contraction
  * (compile with -ffp-contract=off, never -ffast-math), comparisons false on NaN.
