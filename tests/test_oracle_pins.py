@@ -89,6 +89,9 @@ def test_moller_trumbore_and_first_min(gold):
             t = orc.lib.orc_moller_trumbore(np.ascontiguousarray(o[b]), np.ascontiguousarray(d[b]),
                                             np.ascontiguousarray(tris[k]), bary)
             assert bits([t])[0] == bits([gold["mt_t"][k]])[0], (b, r)
+            # the early-return variant the treeless checker (orc_brute_force) is built from: same t, bit for bit
+            t2 = orc.lib.orc_mt_t_only(np.ascontiguousarray(o[b]), np.ascontiguousarray(d[b]), np.ascontiguousarray(tris[k]))
+            assert bits([t2])[0] == bits([gold["mt_t"][k]])[0], (b, r)
             assert np.array_equal(bits(bary), bits([gold["mt_u"][k], gold["mt_v"][k], gold["mt_w"][k]])), (b, r)
             ts.append(t)
             k += 1
@@ -160,3 +163,24 @@ def test_oracle_visit_statistics_equal_the_surveys_probe_of_the_compiled_referen
     c, k, cam, H, W, spp = survey_plate()
     w = orc.Scene([c], [k]).render(*cam, H, W, spp, rng=orc.Rng())
     check_survey_stats(w["nodes"], w["tris"], w["hits"], H * W * spp)
+
+
+def test_brute_force_is_the_first_minimum_over_all_rows(gold):
+    """orc_brute_force (threads, hoisted edge vectors) against a plain loop over the pinned row function."""
+    rs = np.random.default_rng(3)
+    tris = rs.uniform(-1, 1, (300, 3, 3)) + np.array([0, 0, -4.0])
+    tris[100:120] = tris[:20]  # duplicates: exact ties, the first index must win
+    d = rs.uniform(-0.3, 0.3, (500, 3)) + np.array([0, 0, -1.0])
+    o = np.zeros(3)
+    t, first, nmin = orc.brute_force(o, d, tris, threads=3)
+    n_tie = 0
+    for r in range(d.shape[0]):
+        ts = np.array([orc.lib.orc_mt_t_only(o, np.ascontiguousarray(d[r]), np.ascontiguousarray(tris[k].reshape(9)))
+                       for k in range(tris.shape[0])])
+        if np.isinf(ts.min()):
+            assert first[r] == -1 and np.isinf(t[r])
+        else:
+            assert first[r] == int(np.argmin(ts)) and bits([t[r]])[0] == bits([ts.min()])[0]
+            assert nmin[r] == int((ts == ts.min()).sum())
+            n_tie += nmin[r] > 1
+    assert (first >= 0).sum() > 100 and n_tie > 5
