@@ -169,7 +169,7 @@ def test_brute_force_is_the_first_minimum_over_all_rows(gold):
     """orc_brute_force (threads, hoisted edge vectors) against a plain loop over the pinned row function."""
     rs = np.random.default_rng(3)
     tris = rs.uniform(-1, 1, (300, 3, 3)) + np.array([0, 0, -4.0])
-    tris[100:120] = tris[:20]  # duplicates: exact ties, the first index must win
+    tris[150:] = tris[:150]  # duplicates: exact ties, the first index must win
     d = rs.uniform(-0.3, 0.3, (500, 3)) + np.array([0, 0, -1.0])
     o = np.zeros(3)
     t, first, nmin = orc.brute_force(o, d, tris, threads=3)
