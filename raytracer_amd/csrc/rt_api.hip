@@ -94,7 +94,13 @@ struct DevBuf {
     size_t cap = 0;  // elements
     int ensure(size_t n) {
         if (n <= cap) return RT_OK;
-        if (p) (void)hipFree(p);
+        // A buffer that grows a second time is likely to grow again (the trees of a deforming mesh gain a few nodes
+        // per timestep): an eighth of headroom, because hipFree waits for the whole device -- in a pipelined frame
+        // loop that is one frame time per call, every call.  The first allocation is exact.
+        if (p) {
+            (void)hipFree(p);
+            n += n / 8;
+        }
         p = nullptr;
         cap = 0;
         hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(n, 1) * sizeof(T));
@@ -2343,10 +2349,13 @@ int rt_render_scene(int image_height, int image_width, int number_of_samples, co
             return b;
         });
     };
-    // RT_DRIVER_TIMING=1: per-phase wall time of this call on stderr (tuning aid)
+    // RT_DRIVER_TIMING=1: per-phase wall time of this call on stderr (tuning aid); =2: also the host's timeline frame by
+    // frame (when each enqueue, read-back and wait for a build began and ended)
     const bool timing = opt("RT_DRIVER_TIMING") != nullptr;
+    const bool trace = timing && std::atoi(opt("RT_DRIVER_TIMING")) >= 2;
     double t_wait = 0, t_upload = 0, t_render = 0, t_down = 0, t_write = 0;
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_job0 = now();
     std::deque<std::future<Built>> pending;
     size_t next_step = 0;
     auto top_up = [&]() {
@@ -2398,6 +2407,7 @@ int rt_render_scene(int image_height, int image_width, int number_of_samples, co
             Built b = pending.front().get();
             pending.pop_front();
             t_wait += now() - t0;
+            if (trace) std::fprintf(stderr, "    wait for build of t%d %.3f .. %.3f ms\n", t_new, (t0 - t_job0) * 1e3, (now() - t_job0) * 1e3);
             top_up();
             if (!b.sc) {
                 const std::string msg = b.err;
@@ -2442,6 +2452,7 @@ int rt_render_scene(int image_height, int image_width, int number_of_samples, co
         // written while this one renders
         if ((rc = render_frame(c, &p, pipeline))) return bail(rc);
         t_render += now() - t1;
+        if (trace) std::fprintf(stderr, "  f%lld t%d c%d: enqueue %.3f .. %.3f ms\n", (long long)q, t, cam, (t1 - t_job0) * 1e3, (now() - t_job0) * 1e3);
         auto frame_path = [&](int tt, int cc) {
             // cpp/rtmain.cpp:58-60: rtimage_<timestep>_cam<camera>.ppm, zero-based
             return std::string(output_directory) + "/rtimage_" + std::to_string(tt) + "_cam" + std::to_string(cc) + ".ppm";
@@ -2460,6 +2471,7 @@ int rt_render_scene(int image_height, int image_width, int number_of_samples, co
                 uint8_t* dst = rgb2[wbuf].data();
                 if ((rc = download_prev_rgb(c, dst, rgb_bytes))) return bail(rc);
                 t_down += now() - t1;
+                if (trace) std::fprintf(stderr, "      download of previous frame %.3f .. %.3f ms\n", (t1 - t_job0) * 1e3, (now() - t_job0) * 1e3);
                 t1 = now();
                 write_async(frame_path(prev_t, prev_cam), dst);
                 t_write += now() - t1;

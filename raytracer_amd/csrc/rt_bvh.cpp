@@ -17,6 +17,7 @@
 // `int` strides overflow past 2^31 doubles).
 #include "rt_bvh.hpp"
 
+#include <emmintrin.h>
 #include <sched.h>
 
 #include <algorithm>
@@ -31,12 +32,81 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <map>
 #include <memory>
 #include <stdexcept>
 #include <string>
 #include <thread>
 
 namespace rt {
+
+// ---- recycled blocks of the big host arrays (see rt_bvh.hpp) ----
+namespace {
+struct BlockPool {
+    std::mutex mu;
+    std::map<size_t, std::vector<void*>> free_lists;  // class size -> blocks
+    size_t cached = 0;
+    size_t cap = [] {
+        const char* e = std::getenv("RT_HOST_POOL_BYTES");
+        return e ? static_cast<size_t>(std::max(0.0, std::atof(e))) : (size_t(4) << 30);
+    }();
+    ~BlockPool() {
+        for (auto& kv : free_lists)
+            for (void* p : kv.second) ::operator delete(p);
+    }
+};
+BlockPool& block_pool() {
+    static BlockPool* p = new BlockPool();  // (leaked on purpose: vectors with static storage may outlive a static pool)
+    return *p;
+}
+constexpr size_t kPoolMin = size_t(64) << 10;
+size_t pool_class(size_t bytes) {  // round up to an eighth of a power of two
+    size_t p2 = kPoolMin;
+    while (p2 < bytes) p2 <<= 1;
+    const size_t step = p2 >> 4;  // sixteenth of the upper power = eighth of the lower one
+    return (bytes + step - 1) / step * step;
+}
+}  // namespace
+
+void* flat_alloc(size_t bytes) {
+    if (bytes < kPoolMin) return ::operator new(bytes);
+    const size_t cls = pool_class(bytes);
+    BlockPool& bp = block_pool();
+    if (bp.cap) {
+        std::lock_guard<std::mutex> lk(bp.mu);
+        auto it = bp.free_lists.find(cls);
+        if (it != bp.free_lists.end() && !it->second.empty()) {
+            void* p = it->second.back();
+            it->second.pop_back();
+            bp.cached -= cls;
+            return p;
+        }
+    }
+    return ::operator new(cls);
+}
+
+void flat_free(void* p, size_t bytes) noexcept {
+    if (!p) return;
+    if (bytes < kPoolMin) {
+        ::operator delete(p);
+        return;
+    }
+    const size_t cls = pool_class(bytes);
+    BlockPool& bp = block_pool();
+    {
+        std::lock_guard<std::mutex> lk(bp.mu);
+        if (bp.cached + cls <= bp.cap) {
+            try {
+                bp.free_lists[cls].push_back(p);
+                bp.cached += cls;
+                return;
+            } catch (...) {
+            }
+        }
+    }
+    ::operator delete(p);
+}
+
 namespace {
 
 constexpr double kInf = std::numeric_limits<double>::infinity();
@@ -48,18 +118,22 @@ struct Box {
         mn[0] = mn[1] = mn[2] = kInf;
         mx[0] = mx[1] = mx[2] = -kInf;
     }
-    // std::min(a,b) = (b<a)?b:a ; std::max(a,b) = (a<b)?b:a  (NaN / signed-zero behaviour kept)
+    // std::min(a,b) = (b<a)?b:a ; std::max(a,b) = (a<b)?b:a  (NaN / signed-zero behaviour kept).  Two components at a
+    // time with SSE2 (x86-64 baseline): MINPD(p, m) is (p < m) ? p : m and MAXPD(p, m) is (p > m) ? p : m lane by
+    // lane -- the second operand whenever the comparison is false, NaNs and equal zeros included -- i.e. exactly the
+    // two expressions above with p the incoming value and m the running extreme.
     void add_point(const double* p) {
-        for (int i = 0; i < 3; ++i) {
-            mn[i] = (p[i] < mn[i]) ? p[i] : mn[i];
-            mx[i] = (mx[i] < p[i]) ? p[i] : mx[i];
-        }
+        const __m128d p01 = _mm_loadu_pd(p);
+        _mm_storeu_pd(mn, _mm_min_pd(p01, _mm_loadu_pd(mn)));
+        _mm_storeu_pd(mx, _mm_max_pd(p01, _mm_loadu_pd(mx)));
+        mn[2] = (p[2] < mn[2]) ? p[2] : mn[2];
+        mx[2] = (mx[2] < p[2]) ? p[2] : mx[2];
     }
     void add_box(const Box& o) {
-        for (int i = 0; i < 3; ++i) {
-            mn[i] = (o.mn[i] < mn[i]) ? o.mn[i] : mn[i];
-            mx[i] = (mx[i] < o.mx[i]) ? o.mx[i] : mx[i];
-        }
+        _mm_storeu_pd(mn, _mm_min_pd(_mm_loadu_pd(o.mn), _mm_loadu_pd(mn)));
+        mn[2] = (o.mn[2] < mn[2]) ? o.mn[2] : mn[2];
+        mx[0] = (mx[0] < o.mx[0]) ? o.mx[0] : mx[0];
+        _mm_storeu_pd(mx + 1, _mm_max_pd(_mm_loadu_pd(o.mx + 1), _mm_loadu_pd(mx + 1)));
     }
     double extent(int axis) const {
         double r = mx[axis] - mn[axis];
@@ -296,9 +370,33 @@ Box range_box(const Elements& el, const int32_t* idx, int64_t first, int64_t cou
     return b;
 }
 
+// Boxes of the two sides of a partition, gathered during the partition pass itself instead of by
+// separate scans.  A union is a set of exact min/max, so the order of accumulation can only show in the
+// SIGN of a zero extreme (+0 and -0 compare equal; the serial scans keep the first one met): a box
+// with any component equal to zero is therefore not trusted (`ok` false) and recomputed by the
+// ordered scan, which keeps the tree bit-identical to the serial reference build.
+struct Sides {
+    Box box[2], cent[2];
+    bool box_ok[2] = {false, false}, cent_ok[2] = {false, false};
+};
+
+bool no_zero_component(const Box& b) {
+    for (int i = 0; i < 3; ++i)
+        if (b.mn[i] == 0.0 || b.mx[i] == 0.0) return false;
+    return true;
+}
+
 // Decides axis and position; returns false only for count <= 2 (rtbvh.cpp:140).
+// `sides` (ranges below kParMin): the binning pass also keeps every bin's centroid bounds, and when the chosen
+// boundary separates the elements exactly as the partition's own test `centroid < position` will -- every centroid
+// of the bins up to it is below the position, none of the others is (checked on the bins' bounds; the two can differ
+// only by a rounding of the bin index) -- the two sides' boxes and centroid bounds are the unions of the bins' and
+// *sides_ready is set: the partition pass then only compares and swaps.  (Unions of exact min/max: the same values
+// as the reference's scan over the partitioned range, except for the sign of a zero -- see Sides.)
 bool choose_split(const Elements& el, const int32_t* idx, int64_t first, int64_t count, const Box& parent,
-                  const Box* cb_known, int& axis_out, double& pos_out, int64_t& fallbacks) {
+                  const Box* cb_known, int& axis_out, double& pos_out, int64_t& fallbacks, Sides* sides = nullptr,
+                  bool* sides_ready = nullptr) {
+    if (sides_ready) *sides_ready = false;
     if (count <= 2) return false;
     Box cb;
     cb.reset();
@@ -335,7 +433,7 @@ bool choose_split(const Elements& el, const int32_t* idx, int64_t first, int64_t
         return true;
     }
 
-    Box bin_box[kBins];
+    Box bin_box[kBins], bin_cent[kBins];
     uint32_t bin_cnt[kBins];
     for (int b = 0; b < kBins; ++b) {
         bin_box[b].reset();
@@ -343,7 +441,19 @@ bool choose_split(const Elements& el, const int32_t* idx, int64_t first, int64_t
     }
     const double inv_ext = 1.0 / ext;
     const double cmin = cb.mn[axis];
-    if (count < kParMin) {  // the common case: straight into the bins, nothing on the heap
+    const bool with_cent = sides != nullptr && count < kParMin;
+    if (with_cent) {
+        for (int b = 0; b < kBins; ++b) bin_cent[b].reset();
+        for (int64_t i = first; i < first + count; ++i) {
+            const double* cc = elem_cent(el, idx, i);
+            double t = (cc[axis] - cmin) * inv_ext;
+            int b = static_cast<int>(t * kBins);
+            if (b == kBins) b = kBins - 1;
+            bin_cnt[b]++;
+            bin_box[b].add_box(elem_box(el, idx, i));
+            bin_cent[b].add_point(cc);
+        }
+    } else if (count < kParMin) {  // straight into the bins, nothing on the heap
         for (int64_t i = first; i < first + count; ++i) {
             double t = (elem_cent(el, idx, i)[axis] - cmin) * inv_ext;
             int b = static_cast<int>(t * kBins);
@@ -400,7 +510,10 @@ bool choose_split(const Elements& el, const int32_t* idx, int64_t first, int64_t
     run.reset();
     n = 0;
     for (int b = 0; b < kBins - 1; ++b) {
-        if (bin_cnt[b] > 0) run.add_box(bin_box[b]);
+        // (a boundary behind an empty bin separates the same two sets as the one before it: the same cost, which
+        // is never STRICTLY lower -- not evaluated)
+        if (bin_cnt[b] == 0) continue;
+        run.add_box(bin_box[b]);
         n += bin_cnt[b];
         const uint32_t nl = n, nr = rcnt[b + 1];
         if (nl == 0 || nr == 0) continue;
@@ -418,22 +531,30 @@ bool choose_split(const Elements& el, const int32_t* idx, int64_t first, int64_t
     }
     const double width = ext / kBins;
     pos_out = cmin + width * (best_bin + 1);
-    return true;
-}
-
-// Boxes of the two sides of a partition, gathered during the partition pass itself instead of by
-// separate scans.  A union is a set of exact min/max, so the order of accumulation can only show in the
-// SIGN of a zero extreme (+0 and -0 compare equal; the serial scans keep the first one met): a box
-// with any component equal to zero is therefore not trusted (`ok` false) and recomputed by the
-// ordered scan, which keeps the tree bit-identical to the serial reference build.
-struct Sides {
-    Box box[2], cent[2];
-    bool box_ok[2] = {false, false}, cent_ok[2] = {false, false};
-};
-
-bool no_zero_component(const Box& b) {
-    for (int i = 0; i < 3; ++i)
-        if (b.mn[i] == 0.0 || b.mx[i] == 0.0) return false;
+    if (with_cent) {
+        Box lb, rb, lc, rc;
+        lb.reset();
+        rb.reset();
+        lc.reset();
+        rc.reset();
+        for (int b = 0; b < kBins; ++b) {
+            if (bin_cnt[b] == 0) continue;
+            (b <= best_bin ? lb : rb).add_box(bin_box[b]);
+            (b <= best_bin ? lc : rc).add_box(bin_cent[b]);
+        }
+        // both sides are non-empty here (the boundary was valid); the partition's test is `centroid < pos_out`
+        if (lc.mx[axis] < pos_out && !(rc.mn[axis] < pos_out)) {
+            sides->box[0] = lb;
+            sides->box[1] = rb;
+            sides->cent[0] = lc;
+            sides->cent[1] = rc;
+            sides->box_ok[0] = no_zero_component(lb);
+            sides->box_ok[1] = no_zero_component(rb);
+            sides->cent_ok[0] = no_zero_component(lc);
+            sides->cent_ok[1] = no_zero_component(rc);
+            *sides_ready = true;
+        }
+    }
     return true;
 }
 
@@ -620,9 +741,11 @@ int64_t partition(const Elements& el, int32_t* idx, int64_t first, int64_t count
                   const Box* cb_known, int64_t& fallbacks, Sides* sides) {
     int axis = 0;
     double pos = 0.0;
-    if (!choose_split(el, idx, first, count, parent, cb_known, axis, pos, fallbacks)) return -1;
-    int64_t mid = first, end = first + count;
     static const bool fold = std::getenv("RT_NO_FOLD") == nullptr;
+    bool sides_ready = false;
+    if (!choose_split(el, idx, first, count, parent, cb_known, axis, pos, fallbacks, fold ? sides : nullptr, &sides_ready))
+        return -1;
+    int64_t mid = first, end = first + count;
     static const bool par_partition = std::getenv("RT_SERIAL_PARTITION") == nullptr;
     if (par_partition && count >= kParMin && Pool::get().width() > 1) {
         const int64_t nl = partition_closed_form(
@@ -632,7 +755,7 @@ int64_t partition(const Elements& el, int32_t* idx, int64_t first, int64_t count
         if (nl == 0 || nl == count) return -1;
         return nl;
     }
-    if (fold && sides && count < kParMin) {
+    if (fold && sides && count < kParMin && !sides_ready) {
         Box lb, rb, lc, rc;
         lb.reset();
         rb.reset();
@@ -706,7 +829,7 @@ struct Deferred {
     int64_t insert_pos;  // nodes.size() when the root was popped
 };
 
-void expand(std::vector<HostNode>& nodes, const Elements& el, int32_t* idx, int max_leaf, int64_t& fallbacks,
+void expand(FlatVec<HostNode>& nodes, const Elements& el, int32_t* idx, int max_leaf, int64_t& fallbacks,
             int64_t defer_below, std::vector<Deferred>* deferred) {
     std::vector<Task> stack;
     {
@@ -767,7 +890,7 @@ void expand(std::vector<HostNode>& nodes, const Elements& el, int32_t* idx, int 
 // loop would have given them: the loop numbers a node's descendants contiguously from the moment
 // the node is popped, so a subtree's block starts at its insert_pos plus the sizes of the blocks
 // spliced in before it.  The result is identical to the serial build, node for node.
-void build_tree(std::vector<HostNode>& nodes, const Elements& el, int32_t* idx, int64_t n_elem, int max_leaf,
+void build_tree(FlatVec<HostNode>& nodes, const Elements& el, int32_t* idx, int64_t n_elem, int max_leaf,
                 int64_t& fallbacks) {
     nodes.clear();
     HostNode root{};
@@ -865,11 +988,11 @@ void build_tree(std::vector<HostNode>& nodes, const Elements& el, int32_t* idx, 
 
     const double t_tree1 = now_s();
     const int64_t nd = static_cast<int64_t>(deferred.size());
-    std::vector<std::vector<HostNode>> sub(static_cast<size_t>(nd));
+    std::vector<FlatVec<HostNode>> sub(static_cast<size_t>(nd));
     std::vector<int64_t> sub_fallbacks(static_cast<size_t>(nd), 0);
     Pool::get().parallel_for(nd, [&](int64_t i) {
         const Deferred& d = deferred[i];
-        std::vector<HostNode>& v = sub[i];
+        FlatVec<HostNode>& v = sub[i];
         v.reserve(static_cast<size_t>(d.count) * 2 / std::max(1, max_leaf - 1) + 8);
         v.push_back(top[d.node]);  // local root (index 0); descendants get local indices 1, 2, ...
         expand(v, el, idx, max_leaf, sub_fallbacks[i], 0, nullptr);
@@ -906,7 +1029,7 @@ void build_tree(std::vector<HostNode>& nodes, const Elements& el, int32_t* idx, 
         nodes[p + shift_at[p]] = n;
     }
     Pool::get().parallel_for(nd, [&](int64_t i) {
-        const std::vector<HostNode>& v = sub[i];
+        const FlatVec<HostNode>& v = sub[i];
         const int64_t base = block_start[i] - 1;  // local index L >= 1  ->  base + L
         HostNode& r = nodes[deferred[i].node + shift_at[deferred[i].node]];
         r = v[0];

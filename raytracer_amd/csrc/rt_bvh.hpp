@@ -23,9 +23,43 @@ struct HostNode {
     int32_t first;  // BLAS: node_minimum_element_index; TLAS: min_blas_idx
 };
 
+// Blocks of the big host arrays (element records, index arrays, tree nodes, the flattened scene) are RECYCLED: a job
+// builds a scene of the same shape for every timestep, and a fresh block per build is first-touch page faults on
+// every megabyte of it (the kernel zeroes each page: at 8 x 32,768 triangles a fifth of a build's CPU time).  Freed
+// blocks of >= 64 KB go to per-size lists (sizes rounded up to eighths of a power of two) and are handed out again;
+// the cache holds at most RT_HOST_POOL_BYTES (default 4 GiB, 0: off) and gives the rest back to the C++ heap.
+void* flat_alloc(size_t bytes);
+void flat_free(void* p, size_t bytes) noexcept;
+
+// std::vector allocator that default-initialises (leaves trivially constructible elements untouched)
+// on resize: the big flat arrays are written exactly once, by several threads, right after they are
+// sized; zero-filling them first would be a serial pass over a gigabyte.
+template <class T>
+struct NoInitAlloc {
+    using value_type = T;
+    NoInitAlloc() = default;
+    template <class U>
+    NoInitAlloc(const NoInitAlloc<U>&) {}
+    T* allocate(size_t n) { return static_cast<T*>(flat_alloc(n * sizeof(T))); }
+    void deallocate(T* p, size_t n) { flat_free(p, n * sizeof(T)); }
+    template <class U, class... A>
+    void construct(U* p, A&&... a) {
+        if constexpr (sizeof...(A) == 0)
+            ::new (static_cast<void*>(p)) U;
+        else
+            ::new (static_cast<void*>(p)) U(std::forward<A>(a)...);
+    }
+    template <class U>
+    bool operator==(const NoInitAlloc<U>&) const { return true; }
+    template <class U>
+    bool operator!=(const NoInitAlloc<U>&) const { return false; }
+};
+template <class T>
+using FlatVec = std::vector<T, NoInitAlloc<T>>;
+
 struct HostBlas {
-    std::vector<HostNode> nodes;
-    std::vector<int32_t> sorted_to_elem;  // mesh_element_indices after the build
+    FlatVec<HostNode> nodes;
+    FlatVec<int32_t> sorted_to_elem;  // mesh_element_indices after the build
     int32_t mesh = -1;
     double mn[3], mx[3];
     int64_t midpoint_fallbacks = 0;
@@ -59,35 +93,9 @@ constexpr uint32_t DESC_NONE = 0xFFFFFFFFu;  // never a real descriptor (< 2^28 
 constexpr int64_t MAX_DEV_NODES = (1ll << 29) - 2;
 constexpr int64_t MAX_TRIS = (1ll << 28) - 1;
 
-// std::vector allocator that default-initialises (leaves trivially constructible elements untouched)
-// on resize: the big flat arrays are written exactly once, by several threads, right after they are
-// sized; zero-filling them first would be a serial pass over a gigabyte.
-template <class T>
-struct NoInitAlloc {
-    using value_type = T;
-    NoInitAlloc() = default;
-    template <class U>
-    NoInitAlloc(const NoInitAlloc<U>&) {}
-    T* allocate(size_t n) { return static_cast<T*>(::operator new(n * sizeof(T))); }
-    void deallocate(T* p, size_t) { ::operator delete(p); }
-    template <class U, class... A>
-    void construct(U* p, A&&... a) {
-        if constexpr (sizeof...(A) == 0)
-            ::new (static_cast<void*>(p)) U;
-        else
-            ::new (static_cast<void*>(p)) U(std::forward<A>(a)...);
-    }
-    template <class U>
-    bool operator==(const NoInitAlloc<U>&) const { return true; }
-    template <class U>
-    bool operator!=(const NoInitAlloc<U>&) const { return false; }
-};
-template <class T>
-using FlatVec = std::vector<T, NoInitAlloc<T>>;
-
 struct Scene {
     // host tree
-    std::vector<HostNode> tlas;       // reference numbering
+    FlatVec<HostNode> tlas;           // reference numbering
     std::vector<HostBlas> slots;      // tlas.blases: *stored* order (rtbvh.cpp:544-561, quirk 1)
     std::vector<int64_t> slot_tri_base;
     // device arrays
