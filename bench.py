@@ -39,18 +39,27 @@ TDEV = "cuda"  # device of the tensors handed to torch.distributed (see RT_BENCH
 
 
 def kernel_source_hash():
-    """sha256 over the sources that determine the kernels' instruction streams.  profiles/summarize_pmc.py stores
-    it with every PMC summary; the bench refuses to price a launch with counters taken from other kernels."""
+    """sha256 of the device code the library carries (the .hip_fatbin section of raytracer_amd/librtgpu.so): the
+    kernels' instruction streams themselves, unchanged by edits to host code or comments.  profiles/summarize_pmc.py
+    stores it with every PMC summary; the bench refuses to price a launch with counters taken from other kernels."""
     import hashlib
-    h = hashlib.sha256()
-    for rel in ("raytracer_amd/csrc/rt_kernels.hip.hpp", "raytracer_amd/csrc/rt_kernels_fp32.hip.hpp",
-                "raytracer_amd/csrc/rt_bvh.hpp", "raytracer_amd/csrc/Makefile"):
-        for line in open(os.path.join(ROOT, rel), "rb").read().splitlines():
-            # whole-line comments and blank lines do not reach the instruction stream
-            t = line.strip()
-            if t and not t.startswith(b"//") and not t.startswith(b"#  ") and not (rel.endswith("Makefile") and t.startswith(b"#")):
-                h.update(t + b"\n")
-    return h.hexdigest()[:16]
+    import struct
+    b = open(os.path.join(ROOT, "raytracer_amd", "librtgpu.so"), "rb").read()
+    if b[:4] != b"\x7fELF" or b[4] != 2:
+        raise RuntimeError("librtgpu.so is not a 64-bit ELF file")
+    shoff = struct.unpack_from("<Q", b, 0x28)[0]
+    shentsize, shnum, shstrndx = struct.unpack_from("<HHH", b, 0x3A)
+
+    def section(i):
+        name, _typ, _flags, _addr, off, size = struct.unpack_from("<IIQQQQ", b, shoff + i * shentsize)
+        return name, off, size
+
+    stroff = section(shstrndx)[1]
+    for i in range(shnum):
+        name, off, size = section(i)
+        if b[stroff + name:b.index(b"\0", stroff + name)] == b".hip_fatbin":
+            return hashlib.sha256(b[off:off + size]).hexdigest()[:16]
+    raise RuntimeError("librtgpu.so has no .hip_fatbin section")
 
 
 def launch_ranks(n):
