@@ -2327,7 +2327,7 @@ int rt_render_scene(int image_height, int image_width, int number_of_samples, co
     // itself parallel over meshes), fewer for big scenes whose flattened copies are large.
     int64_t tris_per_step = 0;
     for (int m = 0; m < n_meshes; ++m) tris_per_step += elem_counts[m];
-    size_t depth = tris_per_step > 4000000 ? 1 : (tris_per_step > 500000 ? 2 : 4);
+    size_t depth = tris_per_step > 4000000 ? 1 : (tris_per_step > 500000 ? 2 : 6);
     if (const char* e = opt("RT_BUILD_AHEAD")) depth = (size_t)std::max(1, std::atoi(e));
     // enough meshes in flight to occupy every core: one thread per tree (least CPU time per timestep, see rt_bvh.cpp)
     const bool serial_trees = int64_t(n_meshes) * int64_t(depth) >= int64_t(rt::host_threads()) && !opt("RT_NO_SERIAL_TREES");

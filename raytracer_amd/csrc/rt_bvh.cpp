@@ -1176,6 +1176,10 @@ Scene* build_scene(int n_meshes, const double* const* coords, const double* cons
     int nt = n_threads <= 0 ? std::min(n_meshes, host_threads()) : std::min(n_threads, n_meshes);
     if (nt <= 1) {
         for (int m = 0; m < n_meshes; ++m) work(m);
+    } else if (n_threads <= 0) {
+        // the process's own pool: the meshes of the timesteps a frame driver keeps in flight queue up behind each other
+        // (the oldest build is served first and finishes first) instead of time-sharing the cores as 8 threads per build
+        Pool::get().parallel_for(n_meshes, [&](int64_t m) { work(static_cast<int>(m)); });
     } else {
         std::vector<std::thread> pool;
         std::vector<std::string> errors(static_cast<size_t>(nt));
