@@ -63,8 +63,11 @@ void rt_host_free(void *p);
 /*   elem_counts[m] = E_m (the reference reads it from                 */
 /*   face_colors.shape(1), rtbvh.cpp:615).  E_m >= 1.                  */
 /* n_threads: meshes are built concurrently on up to n_threads host    */
-/* threads (<= 0: one per mesh, capped at rt_host_threads()); results  */
-/* do not depend on it.                                                */
+/* threads (0: the process's pool of rt_host_threads() threads, big    */
+/* trees split into tasks: least latency of ONE build; < 0: the same   */
+/* pool, every tree built by one thread: least CPU time, for callers   */
+/* that keep several builds in flight on threads of their own, as      */
+/* rt_render_scene does); results do not depend on it.                 */
 /* ------------------------------------------------------------------ */
 rt_scene *rt_scene_build(int n_meshes, const double *const *coords, const double *const *colors,
                          const int64_t *elem_counts, int timestep, int n_threads);

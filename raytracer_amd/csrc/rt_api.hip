@@ -757,7 +757,8 @@ rt_scene* rt_scene_build(int n_meshes, const double* const* coords, const double
             return nullptr;
         }
         std::unique_ptr<rt_scene> h(new rt_scene());
-        h->s.reset(rt::build_scene(n_meshes, coords, colors, elem_counts, timestep, n_threads));
+        // n_threads < 0: the frame driver's mode (several builds in flight, one thread per tree)
+        h->s.reset(rt::build_scene(n_meshes, coords, colors, elem_counts, timestep, std::max(n_threads, 0), n_threads < 0));
         return h.release();
     } catch (const std::exception& e) {
         g_err = std::string("rt_scene_build: ") + e.what();

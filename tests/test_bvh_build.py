@@ -128,6 +128,30 @@ def test_thread_count_does_not_change_the_tree():
             assert np.array_equal(sa[key], sb[key])
 
 
+def test_one_thread_per_tree_mode_with_builds_in_flight_gives_the_same_trees():
+    """n_threads = -1 (include/rtgpu.h): the frame driver's way of building -- every tree by one thread of the pool,
+    several builds in flight on the caller's threads.  Same trees as the task-split build, also for meshes large
+    enough to take the task-split path otherwise (>= 8192 triangles)."""
+    from concurrent.futures import ThreadPoolExecutor
+    cs, ks = [], []
+    for m in range(5):
+        c, k = meshgen.plate(72 + 3 * m, x0=-8.0 + 3.5 * m, y0=-1.0 + 0.3 * m, T=3, sway=0.05)  # 10,368 .. 14,112 triangles
+        cs.append(np.ascontiguousarray(c))
+        ks.append(np.ascontiguousarray(k))
+    want = [ra.HostScene(cs, ks, t, n_threads=1) for t in range(3)]
+    with ThreadPoolExecutor(6) as ex:
+        got = list(ex.map(lambda j: ra.HostScene(cs, ks, j % 3, n_threads=-1), range(12)))
+    for j, g in enumerate(got):
+        w = want[j % 3]
+        tw, tg = w.tlas(), g.tlas()
+        for key in tw:
+            assert np.array_equal(tw[key], tg[key]), key
+        for s in range(5):
+            sw, sg = w.slot(s), g.slot(s)
+            for key in sw:
+                assert np.array_equal(sw[key], sg[key]), (j, s, key)
+
+
 def test_rejects_bad_input():
     c, k = meshgen.plate(4)
     with pytest.raises(ValueError):
