@@ -38,7 +38,8 @@ LOG = []
 
 
 def log(s=""):
-    LOG.append(s)
+    if EXACT:
+        LOG.append(s)
 
 
 def fr(x):
@@ -53,26 +54,32 @@ def show(x):
     return str(f.numerator) if f.denominator == 1 else f"{f.numerator}/{f.denominator}"
 
 
+EXACT = True  # False (build_scene_binary64): binary64 only, decisions may hinge on a rounding, nothing is logged
+
+
 class Both:
-    """A value carried in binary64 (reference order of operations) and as an exact rational."""
+    """A value carried in binary64 (reference order of operations) and, when EXACT, as an exact rational."""
+    __slots__ = ("f", "q")
 
     def __init__(self, f, q=None):
         self.f = float(f)
-        self.q = Fr(f) if q is None else q
+        self.q = (Fr(f) if q is None else q) if EXACT else None
 
     def __add__(self, o):
-        return Both(self.f + o.f, self.q + o.q)
+        return Both(self.f + o.f, self.q + o.q if EXACT else None)
 
     def __sub__(self, o):
-        return Both(self.f - o.f, self.q - o.q)
+        return Both(self.f - o.f, self.q - o.q if EXACT else None)
 
     def __mul__(self, o):
-        return Both(self.f * o.f, self.q * o.q)
+        return Both(self.f * o.f, self.q * o.q if EXACT else None)
 
     def __truediv__(self, o):
-        return Both(self.f / o.f, self.q / o.q)
+        return Both(self.f / o.f, self.q / o.q if EXACT else None)
 
     def lt(self, o, what):
+        if not EXACT:
+            return self.f < o.f
         a, b = self.f < o.f, self.q < o.q
         if a != b:
             sys.exit(f"decision '{what}' depends on rounding: float {self.f!r} < {o.f!r} is {a}, exact is {b}")
@@ -80,7 +87,12 @@ class Both:
             sys.exit(f"tie in '{what}' is not exact in both arithmetics: {self.f!r} vs {o.f!r}")
         return a
 
+    def same(self, o):  # equal values (ties)
+        return self.q == o.q if EXACT else self.f == o.f
+
     def __str__(self):
+        if not EXACT:
+            return repr(self.f)
         q = self.q
         return str(q.numerator) if q.denominator == 1 else f"{q.numerator}/{q.denominator} (={self.f!r})"
 
@@ -148,7 +160,7 @@ def binned_sah_split(count, lo, cent, boxes, idx, msgs):  # rtbvh.cpp:132-247 ->
             axis, e = a, ext[a]
     log(f"    centroid bounds {cb}; extents x={ext[0]} y={ext[1]} z={ext[2]} -> axis {'xyz'[axis]}, extent {e}")
     if e.f == 0:  # :169-173 -> midpoint_split :122-130
-        assert e.q == 0
+        assert not EXACT or e.q == 0
         msgs.append("SAH splitting failed. Trying midpoint instead.")
         pos = B(cb.mn[axis]) + e * B(0.5)
         FLAGS.add("extent0_midpoint")
@@ -161,8 +173,8 @@ def binned_sah_split(count, lo, cent, boxes, idx, msgs):  # rtbvh.cpp:132-247 ->
         el = idx[i]
         t = (cent[el][axis] - B(cb.mn[axis])) * inv
         tb = t * B(float(NUM_BINS))
-        bf, bq = int(tb.f), int(tb.q)  # static_cast<int>: truncation (values are >= 0)
-        if bf != bq:
+        bf = int(tb.f)  # static_cast<int>: truncation (values are >= 0)
+        if EXACT and bf != int(tb.q):
             sys.exit(f"bin of element {el} depends on rounding ({tb.f!r} vs {tb.q})")
         b = NUM_BINS - 1 if bf == NUM_BINS else bf  # :185
         bins_n[b] += 1
@@ -195,7 +207,7 @@ def binned_sah_split(count, lo, cent, boxes, idx, msgs):  # rtbvh.cpp:132-247 ->
         cost = B(1.0) + B(2.0) * (al / ap * B(float(nl)) + ar / ap * B(float(nr)))
         costs.append((i, cost))
         lower = best_cost is None or cost.lt(best_cost, f"cost of boundary {i} < best")
-        if best_cost is not None and cost.q == best_cost.q and best != -1:
+        if best_cost is not None and cost.same(best_cost) and best != -1:
             FLAGS.add("cost_tie_with_best")
         log(f"      boundary after bin {i}: left n={nl} area {al}, right n={nr} area {ar} -> cost {cost}"
             + ("  <- new best" if lower else ""))
@@ -206,7 +218,7 @@ def binned_sah_split(count, lo, cent, boxes, idx, msgs):  # rtbvh.cpp:132-247 ->
         pos = B(cb.mn[axis]) + e * B(0.5)
         FLAGS.add("no_valid_bin_midpoint")
         return True, axis, pos
-    ties = [i for i, c in costs if c.q == best_cost.q]
+    ties = [i for i, c in costs if c.same(best_cost)]
     if len(ties) > 1:
         log(f"    boundaries {ties} tie at the lowest cost {best_cost}: the first, {best}, wins (rtbvh.cpp:231, strict <)")
     width = e / B(float(NUM_BINS))  # :243
@@ -280,7 +292,7 @@ def build_scene(meshes):
             # compute_element_centroid_tri3 rtbvh.h:153-160: (a + b + c) / 3.0, left to right
             c = [(B(t[0][i]) + B(t[1][i]) + B(t[2][i])) / B(3.0) for i in range(3)]
             for v in c:
-                if Fr(v.f) != v.q:
+                if EXACT and Fr(v.f) != v.q:
                     sys.exit("a centroid is not exactly representable: choose other coordinates")
             cent.append(c)
             b = AABB()
@@ -318,6 +330,19 @@ def build_scene(meshes):
     if any(g["box_of_meshes"] != g["walks_meshes"] for g in guards.values()):
         FLAGS.add("quirk1_active")
     return dict(tlas=tnodes, blas_indices=bidx, slots=slots, blases=blases, messages=len(msgs), guards=guards)
+
+
+def build_scene_binary64(meshes):
+    """The same line-by-line statement in binary64 alone, for inputs whose decisions MAY hinge on a rounding (irregular
+    meshes of a few thousand triangles: tests/test_tree_fixtures.py compares both builders with it node for node).
+    meshes: list of (E, 3, 3) nested lists / arrays.  -> build_scene's dict, boxes as six floats."""
+    global EXACT
+    keep = EXACT
+    EXACT = False
+    try:
+        return build_scene([[[[float(x) for x in v] for v in t] for t in tris] for tris in meshes])
+    finally:
+        EXACT = keep
 
 
 def export(name, meshes, built, probes):

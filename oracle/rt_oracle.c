@@ -30,12 +30,14 @@
  *     hand-derivable fixtures (oracle/derive_tree_fixtures.py, a line-by-line third
  *     statement evaluated in binary64 and in exact rationals; derivation in
  *     tests/golden/tree_fixtures_derivation.txt), tests/test_tree_fixtures.py;
+ *     the same statement in binary64 alone on irregular meshes of a few thousand
+ *     triangles (decisions on roundings and ties), node for node;
  *   - the walk's hit ids against orc_brute_force below -- every triangle tested
  *     with the pinned Moller-Trumbore row, no tree -- tests/test_treeless.py;
  *   - the survey's visit statistics of the compiled reference (43.9 / 4.39 / 0.906).
- * Still unpinned: builder decisions that hinge on a rounding on large irregular
- * trees, and whole images against a file of the reference (it ships none that can
- * be regenerated).
+ * Still unpinned by anything reference-derived: builder decisions that hinge on a
+ * rounding (three statements of one reading of the source agree there), and whole
+ * images against a file of the reference (it ships none that can be regenerated).
  *
  * All arithmetic is IEEE binary64, round-to-nearest-even, no FMA contraction
  * (compile with -ffp-contract=off, never -ffast-math), comparisons false on NaN.

@@ -94,6 +94,70 @@ def test_fixtures_take_the_branches_they_were_made_for():
     assert b["count"][3:5] == [2, 4]  # the mirror-image cost tie went to the FIRST boundary (2 | 4, not 4 | 2)
 
 
+def literal_statement():
+    import importlib.util
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle", "derive_tree_fixtures.py")
+    spec = importlib.util.spec_from_file_location("derive_tree_fixtures", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def irregular_scenes():
+    """Inputs whose decisions DO hinge on roundings and ties: random soups (with exact duplicates), a regular grid
+    (thousands of equal centroid coordinates, centroids on bin borders), a sliver-thin sheet, several meshes."""
+    from raytracer_amd import meshgen
+    soup, _ = meshgen.random_soup(1500, seed=21, extent=7.0, size=0.9)
+    soup[0, 200:260] = soup[0, :60]  # exact duplicates: cost ties
+    soup[0, 300:306] = soup[0, 0]  # eight copies of one triangle: an unsplittable clump (extent 0 -> midpoint -> abort)
+    grid, _ = meshgen.plate(24)  # 1152 triangles on a regular grid
+    thin, _ = meshgen.random_soup(700, seed=5, extent=3.0, size=0.4)
+    thin[0, :, :, 2] *= 1e-9  # nearly planar: tiny extents on one axis
+    thin[0, :, :, 0] += 11.0
+    far, _ = meshgen.plate(9, x0=-14.0, y0=6.0)
+    s2, _ = meshgen.random_soup(400, seed=77, extent=2.0, size=0.3)
+    s2[0, :, :, 1] -= 9.0
+    yield "soup", [soup]
+    yield "grid", [grid]
+    yield "five_meshes", [soup, grid, thin, far, s2]
+
+
+@pytest.mark.parametrize("name,meshes", list(irregular_scenes()), ids=[n for n, _ in irregular_scenes()])
+def test_both_builders_equal_the_literal_statement_on_irregular_meshes(name, meshes):
+    """The fixtures above are chosen so that no decision hinges on a rounding.  Here the same line-by-line statement
+    of rtbvh.cpp (oracle/derive_tree_fixtures.py, binary64 only) is run on irregular meshes of a few thousand
+    triangles, where bin indices, cost comparisons and `centroid < split` do fall on roundings and ties: the oracle's
+    builder and the product's (1 and 4 threads, and the frame driver's one-thread-per-tree mode) must produce its
+    trees node for node -- boxes bit for bit, sorted order, slot order, message count."""
+    lit = literal_statement().build_scene_binary64([m[0] for m in meshes])
+    coords = [np.ascontiguousarray(m[:1]) for m in meshes]
+    colors = [np.full((1, c.shape[1], 3), 0.5) for c in coords]
+
+    def nodes_of(nodes):
+        return dict(boxes=[n["box"].six() for n in nodes], count=[n["count"] for n in nodes],
+                    left=[n["left"] for n in nodes], min_idx=[n["min_idx"] for n in nodes])
+
+    want_tlas = nodes_of(lit["tlas"])
+    builders = [("oracle", lambda: orc.Scene(coords, colors))]
+    for nt in (1, 4, -1):
+        builders.append((f"product n_threads={nt}", lambda nt=nt: ra.HostScene(coords, colors, 0, n_threads=nt)))
+    for who, make in builders:
+        sc = make()
+        t = sc.tlas()
+        check_nodes(dict(boxes=t["boxes"], left=t["left"], count=t["blas_count"], min_idx=t["min_blas_idx"]), want_tlas,
+                    f"{who}: TLAS")
+        msgs = sc.midpoint_msgs if who == "oracle" else sc.info.midpoint_fallbacks
+        assert msgs == lit["messages"], who
+        for s, mesh in enumerate(lit["slots"]):
+            got = sc.slot(s)
+            assert got["mesh"] == mesh, f"{who}: slot {s}"
+            want = lit["blases"][mesh]
+            check_nodes(got, nodes_of(want["nodes"]), f"{who}: slot {s} = mesh {mesh}")
+            assert list(got["indices"]) == want["indices"], f"{who}: sorted order of mesh {mesh}"
+    if name == "soup":
+        assert lit["messages"] >= 1  # the duplicates end in a midpoint fallback somewhere
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("fx", FIXTURES, ids=[f["name"] for f in FIXTURES])
 def test_gpu_walk_reports_the_hand_derived_hits(fx):
