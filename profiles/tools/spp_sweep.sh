@@ -6,7 +6,7 @@ cd "${GRAFT_REPO_ROOT:-.}"
 SPPS=${1:-"50 64"}
 shift
 for s in $SPPS; do
-  out=$(env RT_BENCH_SPP=$s "$@" timeout -k 10 120 python3 bench.py --workload plate1m --steps 5 --warmup 1 --lean 2>/dev/null) || { echo "spp $s failed"; exit 1; }
+  out=$(env RT_BENCH_SPP=$s "$@" timeout -k 10 120 python3 bench.py --workload plate1m --steps 20 --warmup 5 --lean 2>/dev/null) || { echo "spp $s failed"; exit 1; }
   python3 - "$s" "$out" <<'PY'
 import json,sys
 d=json.loads(sys.argv[2]); r=d["roofline"]

@@ -52,7 +52,10 @@ def pinned_empty(shape, dtype=np.float64):
 
 class HostScene:
     """Acceleration structure of one timestep, built on the host exactly as the reference's
-    build_acceleration_structures (cpp/rtbvh.cpp:590-685) and flattened for the GPU."""
+    build_acceleration_structures (cpp/rtbvh.cpp:590-685) and flattened for the GPU.
+    n_threads: 0 = the library's pool (big trees split into tasks: least latency of one build), > 0 = that many
+    threads over the meshes, < 0 = the pool with one thread per tree (least CPU time; for callers that keep several
+    builds in flight on threads of their own, as rt_render_scene does).  The trees do not depend on it."""
 
     def __init__(self, coords, colors, timestep=0, n_threads=0):
         self._keep = _mesh_arrays(coords, colors)

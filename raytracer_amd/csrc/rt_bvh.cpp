@@ -1169,9 +1169,16 @@ Scene* build_scene(int n_meshes, const double* const* coords, const double* cons
 
     // ---- BLAS per mesh (independent; built concurrently, results do not depend on threads) ----
     auto work = [&](int m) {
-        tl_serial_trees = serial_trees;  // (thread-local: this mesh's worker)
+        const bool outer = tl_serial_trees;  // (thread-local: this mesh's worker, for the length of this tree)
+        tl_serial_trees = serial_trees;
         const int64_t E = elem_counts[m];
-        build_one_blas(blases[m], m, coords[m] + static_cast<int64_t>(timestep) * E * 9, E, mesh_cent[m]);
+        try {
+            build_one_blas(blases[m], m, coords[m] + static_cast<int64_t>(timestep) * E * 9, E, mesh_cent[m]);
+        } catch (...) {
+            tl_serial_trees = outer;
+            throw;
+        }
+        tl_serial_trees = outer;
     };
     int nt = n_threads <= 0 ? std::min(n_meshes, host_threads()) : std::min(n_threads, n_meshes);
     if (nt <= 1) {
