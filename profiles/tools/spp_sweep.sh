@@ -10,6 +10,6 @@ for s in $SPPS; do
   python3 - "$s" "$out" <<'PY'
 import json,sys
 d=json.loads(sys.argv[2]); r=d["roofline"]
-print(f"spp {sys.argv[1]:>4}: kernel {r['kernel_ms']:.3f} ms  {r['kernel_only_mrays_s']/1e3:.2f} Grays/s  step {d['ms_per_step']:.3f} ms  box tests/ray {r['hbm_per_wave']['box_tests_per_ray']:.2f}  tri tests/ray {r['hbm_per_wave']['tri_tests_per_ray']:.2f}  necessary frac {r['frac']:.3f}")
+print(f"spp {sys.argv[1]:>4}: kernel {r['kernel_ms']:.3f} ms  {r['kernel_only_mrays_s']/1e3:.2f} Grays/s  step {d['ms_per_step']:.3f} ms  box tests/ray {r['hbm_per_wave']['box_tests_per_ray']:.2f}  tri tests/ray {r['hbm_per_wave']['tri_tests_per_ray']:.2f}  tri records/batch {r['hbm_per_wave']['tri_records_per_batch']:.2f}  necessary frac {r['frac']:.3f}")
 PY
 done
