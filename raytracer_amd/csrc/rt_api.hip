@@ -2333,8 +2333,10 @@ int rt_render_scene(int image_height, int image_width, int number_of_samples, co
     // enough meshes in flight to occupy every core: one thread per tree (least CPU time per timestep, see rt_bvh.cpp)
     const bool serial_trees = int64_t(n_meshes) * int64_t(depth) >= int64_t(rt::host_threads()) && !opt("RT_NO_SERIAL_TREES");
     auto build_async = [&](int t) {
+        const int64_t ticket = rt::draw_build_ticket();  // (drawn here, in timestep order: the pool serves the oldest build first)
         return std::async(std::launch::async, [=]() {
             Built b;
+            const rt::AdoptBuildTicket adopt(ticket);
             try {
                 std::unique_ptr<rt_scene> h(new rt_scene());
                 h->s.reset(rt::build_scene(n_meshes, coords, colors, elem_counts, t, 0, serial_trees));

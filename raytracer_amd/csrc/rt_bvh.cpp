@@ -227,6 +227,20 @@ std::vector<int> rank_cpu_slice(int threads) {
     return out;
 }
 
+// Oldest build first: every build_scene call draws a ticket, the jobs it (and the tasks of its jobs) hand to the pool
+// carry it, and the workers take the job with the lowest ticket.  A frame driver keeps several timesteps' builds in
+// flight and waits for the OLDEST one: its last passes (TLAS, flatten) must not queue behind the tree builds of the
+// timesteps after it.  -1: no build in progress on this thread (a job then gets a ticket of its own: plain FIFO).
+thread_local int64_t tl_ticket = -1;
+std::atomic<int64_t> g_next_ticket{0};
+struct TicketScope {
+    int64_t outer;
+    TicketScope() : outer(tl_ticket) {
+        if (tl_ticket < 0) tl_ticket = g_next_ticket.fetch_add(1);
+    }
+    ~TicketScope() { tl_ticket = outer; }
+};
+
 class Pool {
 public:
     static Pool& get() {
@@ -243,12 +257,20 @@ public:
         auto job = std::make_shared<Job>();
         job->n = n;
         job->fn = &fn;
+        job->ticket = (tl_ticket >= 0 && !fifo_) ? tl_ticket : g_next_ticket.fetch_add(1);
         const int64_t helpers = std::min<int64_t>(n - 1, static_cast<int64_t>(workers_.size()));
         {
             std::lock_guard<std::mutex> lk(mu_);
-            for (int64_t h = 0; h < helpers; ++h) queue_.push_back(job);
+            auto at = queue_.end();  // behind every entry of the same or an older build
+            while (at != queue_.begin() && (*(at - 1))->ticket > job->ticket) --at;
+            queue_.insert(at, static_cast<size_t>(helpers), job);
         }
-        cv_.notify_all();
+        // (a worker that finds the queue empty goes back to sleep: waking more of them than there are entries would
+        // only cost the wake-ups)
+        if (helpers >= static_cast<int64_t>(workers_.size()))
+            cv_.notify_all();
+        else
+            for (int64_t h = 0; h < helpers; ++h) cv_.notify_one();
         run(*job);
         std::unique_lock<std::mutex> lk(job->mu);
         job->cv.wait(lk, [&] { return job->done.load() == job->n; });
@@ -258,6 +280,7 @@ public:
 private:
     struct Job {
         int64_t n = 0;
+        int64_t ticket = 0;
         const std::function<void(int64_t)>* fn = nullptr;  // valid until done == n (the caller waits)
         std::atomic<int64_t> next{0}, done{0};
         std::mutex mu;
@@ -265,9 +288,11 @@ private:
         std::string error;
     };
     static void run(Job& j) {
+        const int64_t outer = tl_ticket;
+        tl_ticket = j.ticket;  // the jobs this job's tasks hand out belong to the same build
         for (;;) {
             const int64_t i = j.next.fetch_add(1);
-            if (i >= j.n) return;
+            if (i >= j.n) break;
             try {
                 (*j.fn)(i);
             } catch (const std::exception& e) {
@@ -279,6 +304,7 @@ private:
                 j.cv.notify_all();
             }
         }
+        tl_ticket = outer;
     }
     explicit Pool(int n) {
         const std::vector<int> cpus = rank_cpu_slice(n + 1);
@@ -311,12 +337,19 @@ private:
         cv_.notify_all();
         for (auto& t : workers_) t.join();
     }
+    const bool fifo_ = std::getenv("RT_POOL_FIFO") != nullptr;  // (comparison knob: jobs in arrival order)
     std::vector<std::thread> workers_;
     std::mutex mu_;
     std::condition_variable cv_;
     std::deque<std::shared_ptr<Job>> queue_;
     bool stop_ = false;
 };
+
+}  // namespace
+int64_t draw_build_ticket() { return g_next_ticket.fetch_add(1); }
+AdoptBuildTicket::AdoptBuildTicket(int64_t t) : outer(tl_ticket) { tl_ticket = t; }
+AdoptBuildTicket::~AdoptBuildTicket() { tl_ticket = outer; }
+namespace {
 
 // RT_BUILD_TIMING=1: phase times of every large tree on stderr (tuning aid)
 const bool g_build_timing = std::getenv("RT_BUILD_TIMING") != nullptr;
@@ -1163,6 +1196,7 @@ Scene* build_scene(int n_meshes, const double* const* coords, const double* cons
     }
     if (total_tris > MAX_TRIS) throw std::runtime_error("scene exceeds 2^28-1 triangles");
 
+    const TicketScope ticket;  // this build's place in the pool's queue (oldest build first)
     std::unique_ptr<Scene> sc(new Scene());
     std::vector<HostBlas> blases(static_cast<size_t>(n_meshes));
     std::vector<Centroid> mesh_cent(static_cast<size_t>(n_meshes));

@@ -15,6 +15,18 @@ namespace rt {
 // LOCAL_WORLD_SIZE, 1..16; never OMP_NUM_THREADS).
 int host_threads();
 
+// The pool serves the OLDEST build first (every build_scene call draws a ticket; rt_bvh.cpp, Pool).  A caller that
+// starts builds on threads of its own draws the tickets in the order it will wait for the builds, and each thread adopts
+// its ticket for the length of the build.
+int64_t draw_build_ticket();
+struct AdoptBuildTicket {
+    explicit AdoptBuildTicket(int64_t t);
+    ~AdoptBuildTicket();
+    AdoptBuildTicket(const AdoptBuildTicket&) = delete;
+    AdoptBuildTicket& operator=(const AdoptBuildTicket&) = delete;
+    int64_t outer;
+};
+
 // ---- host tree in the reference's numbering (kept for introspection / parity tests) ----
 struct HostNode {
     double mn[3], mx[3];
