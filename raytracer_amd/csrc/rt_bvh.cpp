@@ -1289,6 +1289,7 @@ Scene* build_scene(int n_meshes, const double* const* coords, const double* cons
     sc->prim_elem.resize(static_cast<size_t>(total_tris));
 
     std::vector<int32_t> slot_need(n_slots, 0), slot_max_leaf(n_slots, 0);
+    std::vector<double> slot_max_abs(static_cast<size_t>(n_slots), 0.0);
     std::vector<std::vector<int64_t>> big_leaves(n_slots);  // leaves that need a leaf_ext entry, in sweep order
     Pool::get().parallel_for(n_slots, [&](int64_t s) {
         const HostBlas& b = sc->slots[s];
@@ -1297,16 +1298,29 @@ Scene* build_scene(int n_meshes, const double* const* coords, const double* cons
         const double* kt = colors[b.mesh] + static_cast<int64_t>(timestep) * E * 3;
         const int64_t tb = sc->slot_tri_base[s];
         {
+            // (the largest |coordinate| of the scene is gathered on the way: NaN counts as infinity)
+            std::vector<double> part(static_cast<size_t>(E < kParMin ? 1 : (E + kParChunk - 1) / kParChunk), 0.0);
             int64_t nc = 0;
-            for_chunks(0, E, nc, [&](int64_t, int64_t lo, int64_t hi) {
+            for_chunks(0, E, nc, [&](int64_t c, int64_t lo, int64_t hi) {
+                double m = 0.0;
                 for (int64_t p = lo; p < hi; ++p) {
                     const int64_t e = b.sorted_to_elem[p];
-                    std::memcpy(&sc->tris[(tb + p) * 9], ct + e * 9, 9 * sizeof(double));
+                    double* const dst = &sc->tris[(tb + p) * 9];
+                    std::memcpy(dst, ct + e * 9, 9 * sizeof(double));
                     std::memcpy(&sc->colors[(tb + p) * 3], kt + e * 3, 3 * sizeof(double));
                     sc->prim_mesh[tb + p] = b.mesh;
                     sc->prim_elem[tb + p] = static_cast<int32_t>(e);
+                    for (int j = 0; j < 9; ++j) {
+                        const double a = std::fabs(dst[j]);
+                        if (!(a <= m)) m = (a == a) ? a : kInf;
+                    }
                 }
+                part[static_cast<size_t>(c)] = m;
             });
+            double m = 0.0;
+            for (int64_t c = 0; c < nc; ++c)
+                if (!(part[static_cast<size_t>(c)] <= m)) m = part[static_cast<size_t>(c)];
+            slot_max_abs[static_cast<size_t>(s)] = m;
         }
         const int64_t nb = slot_node_base[s] + 1;
         sc->slot_root[s] = static_cast<int32_t>(nb);
@@ -1381,24 +1395,8 @@ Scene* build_scene(int n_meshes, const double* const* coords, const double* cons
         }
     }
     sc->stack_need = std::max(1, tneed[0]) + 1;
-    {
-        const int64_t nv = static_cast<int64_t>(sc->tris.size());
-        const int64_t max_chunks = nv < kParMin ? 1 : (nv + kParChunk - 1) / kParChunk;
-        std::vector<double> part(static_cast<size_t>(max_chunks), 0.0);
-        int64_t nc = 0;
-        for_chunks(0, nv, nc, [&](int64_t c, int64_t lo, int64_t hi) {
-            double m = 0.0;
-            for (int64_t i = lo; i < hi; ++i) {
-                const double a = std::fabs(sc->tris[i]);
-                if (!(a <= m)) m = (a == a) ? a : kInf;  // NaN -> inf
-            }
-            part[c] = m;
-        });
-        double m = 0.0;
-        for (int64_t c = 0; c < nc; ++c)
-            if (!(part[c] <= m)) m = part[c];
-        sc->max_abs_coord = m;
-    }
+    for (int s = 0; s < n_slots; ++s)
+        if (!(slot_max_abs[static_cast<size_t>(s)] <= sc->max_abs_coord)) sc->max_abs_coord = slot_max_abs[static_cast<size_t>(s)];
 
     sc->build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     if (std::getenv("RT_BUILD_TIMING"))
