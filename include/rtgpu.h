@@ -90,6 +90,12 @@ int rt_scene_info(const rt_scene *scene, rt_scene_info_t *out);
  * of up to max_n elements with random chunk lengths and returns how many differ (0 = identical permutations). */
 int64_t rt_partition_selftest(int64_t cases, uint64_t seed, int max_n);
 
+/* Test seam, host-only.  The jump-ahead works modulo the characteristic polynomial phi of MT19937's one-word
+ * transition (degree 19937).  phi is compiled in (312 words, bit i of word i / 64 = coefficient of x^i);
+ * recompute != 0 derives it afresh from the generator's output with Berlekamp-Massey instead (tens of ms): the two
+ * must be equal.  No counterpart in the reference (std::mt19937 never jumps). */
+int rt_mt_phi(uint64_t *out312, int recompute);
+
 /* Introspection of the host tree in the reference's own numbering (parity tests). */
 int rt_scene_tlas(const rt_scene *scene, double *boxes6, int32_t *blas_count, int32_t *left,
                   int32_t *min_blas_idx);

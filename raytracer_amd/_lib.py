@@ -59,6 +59,7 @@ _PROTOS = {
     "rt_reload_options": (C.c_int, []),
     "rt_option_names": (C.c_char_p, []),
     "rt_partition_selftest": (C.c_int64, [C.c_int64, C.c_uint64, C.c_int]),
+    "rt_mt_phi": (C.c_int, [C.c_void_p, C.c_int]),
     "rt_host_alloc": (_VP, [C.c_size_t]),
     "rt_host_free": (None, [_VP]),
     "rt_scene_build": (_VP, [C.c_int, C.POINTER(_VP), C.POINTER(_VP), _VP, C.c_int, C.c_int]),

@@ -519,6 +519,7 @@ int fill_slot(rt_ctx* c, int k, uint64_t ahead, int rows, int W, int spp, int fr
     if ((rc = sl.d_states.ensure(size_t(pl.n) * rt::MT_N))) return rc;
     if ((rc = sl.d_end.ensure(rt::MT_N))) return rc;
     const double t0 = now_ms();
+    std::future<void> end_poly;  // (joined by its destructor on every early return)
     // a traversal kernel launched earlier may still be reading this slot's pairs
     if (sl.read_pending) HIP_TRY(hipStreamWaitEvent(c->rng_stream, sl.read_done, 0));
     HIP_TRY(hipEventRecord(sl.t0, c->rng_stream));
@@ -540,6 +541,16 @@ int fill_slot(rt_ctx* c, int k, uint64_t ahead, int rows, int W, int spp, int fr
                            (unsigned long long)(pl.stride / 2), (unsigned long long)(pl.total_words / 2));
         HIP_TRY(hipGetLastError());
     } else {
+        // first fill of a shape: the polynomial of the slot's length (needed last, for the end state) is computed by a
+        // helper thread while this thread computes the doubling tree's -- two chains of ~26 squarings mod phi each,
+        // ~9 ms apiece: the first frame of a new shape waits ~10 ms for the host instead of ~19
+        if (c->d_polys.find(pl.total_words) == c->d_polys.end())
+            end_poly = std::async(std::launch::async, [tw = pl.total_words]() {
+                try {
+                    (void)rt::mt_jump_poly(tw);
+                } catch (const std::exception&) {  // (the jump below reports it)
+                }
+            });
         if ((rc = dev_jump(c, c->d_state.p, sl.d_states.p, ahead + (c->pos - c->state_pos)))) return rc;
         if ((rc = launch_jitter(c, sl.d_states.p, pl, sl.buf.p))) return rc;
     }
@@ -551,6 +562,7 @@ int fill_slot(rt_ctx* c, int k, uint64_t ahead, int rows, int W, int spp, int fr
     HIP_TRY(hipEventRecord(sl.done, c->rng_stream));
     // the state at the slot's end is only needed when the slot's last frame has been handed out (a copy on this
     // stream): its jump goes BEHIND the pairs, off the chain the traversal waits for
+    if (end_poly.valid()) end_poly.wait();
     if ((rc = dev_jump(c, sl.d_states.p, sl.d_end.p, pl.total_words))) return rc;
     sl.host_ms = now_ms() - t0;
     sl.pos = c->pos + ahead;
@@ -720,6 +732,16 @@ int rt_reload_options(void) {
     g_options.load();
     return RT_OK;
 }
+int rt_mt_phi(uint64_t* out312, int recompute) {
+    if (!out312) return fail(RT_E_INVALID, "rt_mt_phi: null argument");
+    try {
+        rt::mt_phi_words(out312, recompute != 0);
+    } catch (const std::exception& e) {
+        return fail(RT_E_INVALID, std::string("rt_mt_phi: ") + e.what());
+    }
+    return RT_OK;
+}
+
 int64_t rt_partition_selftest(int64_t cases, uint64_t seed, int max_n) {
     try {
         return rt::partition_selftest(cases, seed, max_n);

@@ -83,10 +83,14 @@ Phi compute_phi() {
     return phi;
 }
 
-const Phi& phi() {
-    static const Phi p = compute_phi();
-    return p;
-}
+// phi is a constant of the generator: its 19938 coefficients are compiled in (rt_mt19937_phi.inc, written by
+// profiles/tools/gen_mt_phi.py from compute_phi() above; tests/test_mt_jump.py checks the table against a fresh
+// Berlekamp-Massey run).  Computing it took 9 ms (GPU box) to 30 ms of the first frame of every process.
+const Phi kPhiTable = {{
+#include "rt_mt19937_phi.inc"
+}};
+
+const Phi& phi() { return kPhiTable; }
 
 inline bool poly_bit(const uint64_t* p, int i) { return (p[i / 64] >> (i % 64)) & 1u; }
 
@@ -175,6 +179,11 @@ std::mutex g_cache_mu;
 std::map<uint64_t, MtPoly> g_cache;
 
 }  // namespace
+
+void mt_phi_words(uint64_t out[312], bool recompute) {
+    const Phi p = recompute ? compute_phi() : phi();
+    std::memcpy(out, p.b, sizeof(p.b));
+}
 
 void mt_seed(MtState& s, uint32_t seed) {
     s.w[0] = seed;

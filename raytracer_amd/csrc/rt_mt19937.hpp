@@ -30,6 +30,11 @@ struct MtPoly {
     uint64_t b[312];
 };
 
+// The characteristic polynomial phi of the generator's one-word transition, bit-packed (bit i of word i/64 = the
+// coefficient of x^i; degree 19937): the compiled-in table, or (recompute) a fresh Berlekamp-Massey run over the
+// generator's output -- the two must agree (selftest).
+void mt_phi_words(uint64_t out[312], bool recompute);
+
 // g = x^stride mod phi  (cached per stride; thread-safe)
 MtPoly mt_jump_poly(uint64_t stride);
 // out = g(A) in   (out may alias in)

@@ -80,3 +80,15 @@ def test_stream_states_stay_correct_once_the_polynomial_cache_is_full():
     g = orc.Rng(5489)
     g.discard(987654)
     assert np.array_equal(oracle_words_from_state(st, 64), g.u32(64))
+
+
+def test_compiled_in_characteristic_polynomial_equals_a_fresh_berlekamp_massey_run():
+    """phi (degree 19937, 135 terms) is a table in the library (rt_mt19937_phi.inc); recomputing it from the
+    generator's own output must give the same 312 words."""
+    from raytracer_amd import _lib as L
+    table, fresh = np.zeros(312, np.uint64), np.zeros(312, np.uint64)
+    L.check(L.lib.rt_mt_phi(table.ctypes.data, 0), "rt_mt_phi")
+    L.check(L.lib.rt_mt_phi(fresh.ctypes.data, 1), "rt_mt_phi")
+    assert np.array_equal(table, fresh)
+    assert (int(table[311]) >> (19937 % 64)) & 1 and int(table[311]) >> (19937 % 64 + 1) == 0  # monic, degree 19937
+    assert sum(bin(int(x)).count("1") for x in table) == 135
