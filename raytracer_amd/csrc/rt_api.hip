@@ -1264,6 +1264,12 @@ struct CutTables {
     int32_t lo = -1;  // < 0: no cuts, every batch walks from the root
 };
 
+// Frames of fewer rays walk from the root (RT_CUT_MIN_RAYS: tuning knob; see make_cuts)
+double cut_min_rays() {
+    const char* mr = opt("RT_CUT_MIN_RAYS");
+    return mr ? std::atof(mr) : 12e6;
+}
+
 // The cut kernels of one launch (cut_level_kernel, level after level) on stream `st`, from the camera-relative boxes
 // the prep kernels have written.  `allowed`: not with visit counters (they count the reference's visit rule), not
 // without min <= max boxes and tame coordinates (the cut's argument rests on the NaN-free slab test).  Allocates
@@ -1277,9 +1283,7 @@ int make_cuts(rt_ctx* c, hipStream_t st, const rt_render_params* p, int tile_log
     // The cut kernels are chains of dependent steps (~0.3 ms however small the image) and save a third to a half of
     // the traversal.  Measured: 2048^2 x 4 spp (16.7 M rays, 1 M triangles) 1.47 -> 1.32 ms per frame with cuts,
     // 400 x 225 x 50 spp (4.5 M rays) 0.30 -> 0.49 ms.
-    const char* mr = opt("RT_CUT_MIN_RAYS");  // (tuning knob)
-    const double min_rays = mr ? std::atof(mr) : 12e6;
-    if (!cuts || !allowed || no_cut || double(rows) * W * spp < min_rays) return RT_OK;
+    if (!cuts || !allowed || no_cut || double(rows) * W * spp < cut_min_rays()) return RT_OK;
     const CutPlan cp = plan_cuts(W, rows, spp, tile_log2);
     rtk::CutArgs ca;
     ca.nodes = cam_nodes;
@@ -1532,8 +1536,9 @@ int render_impl(rt_ctx* c, const rt_render_params* p, bool pipelined) {
     rt_ctx::CamSet* cs = nullptr;
     CutPlan cp;
     // (small frames of small scenes: the two cross-stream dependencies cost more than the ~10 us of prep they hide)
+    // (a frame that gets cuts always overlaps: the cut kernels are chains of dependent steps, ~0.3 ms of latency)
     const bool overlap = opt("RT_NO_PREP_OVERLAP") == nullptr &&  // (comparison knob, read per launch)
-                         (n_smp >= (size_t(1) << 24) || c->n_tris >= (1 << 18));
+                         (n_smp >= (size_t(1) << 24) || c->n_tris >= (1 << 18) || double(n_smp) >= cut_min_rays());
     if (packet_launch) {
         c->cam_idx ^= 1;
         cs = &c->cam[c->cam_idx];
