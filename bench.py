@@ -770,7 +770,8 @@ def main():
                        "sampler": "MT19937 reference stream (GPU GF(2) jump-ahead + jitter kernels, device-resident state)",
                        "hit_ids_written": want_ids, "frames_per_step_per_gpu": 1,
                        "cuts": ("off (RT_NO_CUT)" if os.environ.get("RT_NO_CUT") else
-                                "made per frame for frames >= %g rays" % float(os.environ.get("RT_CUT_MIN_RAYS", 12e6))),
+                                "made per frame: the whole hierarchy for frames >= %g rays, one level at the render tile from %g rays"
+                                % (float(os.environ.get("RT_CUT_MIN_RAYS", 12e6)), float(os.environ.get("RT_CUT1_MIN_RAYS", 2e6)))),
                        "host_threads_per_rank": int(ra.lib.rt_host_threads()),
                        "parallelism": f"frame-sharded x{world}, no collective"},
             "roofline": roofline,

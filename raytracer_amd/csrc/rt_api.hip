@@ -56,7 +56,7 @@ int fail(int code, const std::string& msg) {
 // -- by the first rt_create, or by the first host-only call that needs one -- and again only on rt_reload_options():
 // no render, upload or driver call reaches getenv.  opt("RT_X") returns the value taken then, or null when unset,
 // so each site keeps the meaning it had when it asked the environment itself.
-const char* const kOptionNames[] = {"RT_ADAPT_MIN_WORDS", "RT_ADAPT_RATIO", "RT_BUILD_AHEAD", "RT_BUILD_TIMING", "RT_COUNT_WITH_CUTS", "RT_CUT_LO", "RT_CUT_MIN_RAYS", "RT_CUT_STEP", "RT_CUT_TOP", "RT_CUT_TOPCAP", "RT_DRIVER_TIMING", "RT_FORCE_PERLANE", "RT_INTERLEAVE", "RT_JITTER_SLOT_BYTES", "RT_JITTER_STREAMS", "RT_NO_ADAPT_STREAMS", "RT_NO_CUT", "RT_NO_FRAME_GROUPS", "RT_NO_INTERLEAVE", "RT_NO_LOOKAHEAD", "RT_NO_PAIR64", "RT_NO_PIPELINE", "RT_NO_PREP_OVERLAP", "RT_NO_SERIAL_TREES", "RT_NO_SMALL_TILES", "RT_NO_STATE_REUSE", "RT_NO_TRIM", "RT_PAD64_FROM", "RT_RNG_PRIO", "RT_STAGE_STREAMS", "RT_TILE_LOG2"};
+const char* const kOptionNames[] = {"RT_ADAPT_MIN_WORDS", "RT_ADAPT_RATIO", "RT_BUILD_AHEAD", "RT_BUILD_TIMING", "RT_COUNT_WITH_CUTS", "RT_CUT1_CAP", "RT_CUT1_MIN_RAYS", "RT_CUT_LO", "RT_CUT_MIN_RAYS", "RT_CUT_STEP", "RT_CUT_TOP", "RT_CUT_TOPCAP", "RT_DRIVER_TIMING", "RT_FORCE_PERLANE", "RT_INTERLEAVE", "RT_JITTER_SLOT_BYTES", "RT_JITTER_STREAMS", "RT_NO_ADAPT_STREAMS", "RT_NO_CUT", "RT_NO_FRAME_GROUPS", "RT_NO_INTERLEAVE", "RT_NO_LOOKAHEAD", "RT_NO_PAIR64", "RT_NO_PIPELINE", "RT_NO_PREP_OVERLAP", "RT_NO_SERIAL_TREES", "RT_NO_SMALL_TILES", "RT_NO_STATE_REUSE", "RT_NO_TRIM", "RT_PAD64_FROM", "RT_RNG_PRIO", "RT_STAGE_STREAMS", "RT_TILE_LOG2"};
 constexpr int kNumOptions = (int)(sizeof(kOptionNames) / sizeof(kOptionNames[0]));
 struct OptionTable {
     std::mutex mu;
@@ -127,11 +127,35 @@ struct CutPlan {
     int64_t tiles[32] = {};
     int64_t offset_words[32] = {};
     int64_t total_words = 0;
+    bool single = false;  // cut_mode 1: one level, the render tile's
 };
+
+// How a frame's walk starts, by its number of rays (RT_CUT_MIN_RAYS, RT_CUT1_MIN_RAYS: tuning knobs):
+//   2  the whole hierarchy of cuts down to the finest level a batch can ask for, leaves trimmed (>= 12 M rays);
+//   1  ONE level, the render tile's blocks, straight from the root, untrimmed and with short lists: the cut kernel is
+//      a chain of dependent steps however small the image, and for a 400 x 225 x 50 frame (4.5 M rays) every further
+//      launch and every further refinement step costs more than it takes off the traversal;
+//   0  every batch walks from the root (< 2 M rays).
+double cut_min_rays() {
+    const char* mr = opt("RT_CUT_MIN_RAYS");
+    return mr ? std::atof(mr) : 12e6;
+}
+double cut1_min_rays() {
+    const char* mr = opt("RT_CUT1_MIN_RAYS");
+    return mr ? std::atof(mr) : 2e6;
+}
+int cut_mode(int W, int rows, int spp) {
+    const double rays = double(W) * double(rows) * double(spp);
+    return rays >= cut_min_rays() ? 2 : (rays >= cut1_min_rays() ? 1 : 0);
+}
 
 // Entries a list of level l may hold: coarse levels only hand a starting point down (their blocks are refined
 // again, four times over, by their children), so they stop at half the room.
 int cut_cap(int l, const CutPlan& cp) {
+    if (cp.single) {
+        const int cap1 = opt("RT_CUT1_CAP") ? std::atoi(opt("RT_CUT1_CAP")) : 16;  // (tuning knob)
+        return std::max(1, std::min(cap1, (int)rtk::CUT_CAP));
+    }
     const int top_cap = opt("RT_CUT_TOPCAP") ? std::atoi(opt("RT_CUT_TOPCAP")) : 15;  // (tuning knob)
     return (l > cp.lo + 1) ? std::max(1, std::min(top_cap, (int)rtk::CUT_CAP)) : (int)rtk::CUT_CAP;
 }
@@ -153,6 +177,10 @@ CutPlan plan_cuts(int W, int rows, int spp, int tile_log2) {
     // (tuning knob; never below the render tile's level: a batch looks its cut up at levels lo..tile_log2 and takes
     // the next coarser level that was made, which must exist)
     if (const char* e = opt("RT_CUT_TOP")) cp.top = std::max({cp.lo, tile_log2, std::atoi(e)});
+    if (cut_mode(W, rows, spp) == 1) {
+        cp.single = true;
+        cp.lo = cp.top = tile_log2;
+    }
     int whole = 0;
     while ((1 << whole) < std::max(W, rows)) ++whole;
     cp.top = std::max(cp.lo, std::min(cp.top, std::max(whole, tile_log2)));
@@ -1264,12 +1292,6 @@ struct CutTables {
     int32_t lo = -1;  // < 0: no cuts, every batch walks from the root
 };
 
-// Frames of fewer rays walk from the root (RT_CUT_MIN_RAYS: tuning knob; see make_cuts)
-double cut_min_rays() {
-    const char* mr = opt("RT_CUT_MIN_RAYS");
-    return mr ? std::atof(mr) : 12e6;
-}
-
 // The cut kernels of one launch (cut_level_kernel, level after level) on stream `st`, from the camera-relative boxes
 // the prep kernels have written.  `allowed`: not with visit counters (they count the reference's visit rule), not
 // without min <= max boxes and tame coordinates (the cut's argument rests on the NaN-free slab test).  Allocates
@@ -1283,7 +1305,7 @@ int make_cuts(rt_ctx* c, hipStream_t st, const rt_render_params* p, int tile_log
     // The cut kernels are chains of dependent steps (~0.3 ms however small the image) and save a third to a half of
     // the traversal.  Measured: 2048^2 x 4 spp (16.7 M rays, 1 M triangles) 1.47 -> 1.32 ms per frame with cuts,
     // 400 x 225 x 50 spp (4.5 M rays) 0.30 -> 0.49 ms.
-    if (!cuts || !allowed || no_cut || double(rows) * W * spp < cut_min_rays()) return RT_OK;
+    if (!cuts || !allowed || no_cut || cut_mode(W, rows, spp) == 0) return RT_OK;
     const CutPlan cp = plan_cuts(W, rows, spp, tile_log2);
     rtk::CutArgs ca;
     ca.nodes = cam_nodes;
@@ -1307,7 +1329,7 @@ int make_cuts(rt_ctx* c, hipStream_t st, const rt_render_params* p, int tile_log
         ca.n_tiles = (int32_t)cp.tiles[l];
         ca.cuts = cuts + cp.offset_words[l];
         // the finest level's leaves lose the triangles no ray of the block can hit (cut_trim); RT_NO_TRIM: comparison knob
-        ca.tris = (l == cp.lo && !opt("RT_NO_TRIM")) ? cam_tris : nullptr;
+        ca.tris = (l == cp.lo && !cp.single && !opt("RT_NO_TRIM")) ? cam_tris : nullptr;
         const int64_t patches = int64_t((cp.tiles_x[l] + 7) / 8) * ((cp.tiles[l] / cp.tiles_x[l] + 7) / 8);
         const int per_wg = rtk::CUT_THREADS / 64;  // one 8 x 8 patch of blocks per wave
         hipLaunchKernelGGL(rtk::cut_level_kernel, dim3((unsigned)((patches + per_wg - 1) / per_wg)), dim3(rtk::CUT_THREADS),
@@ -1538,7 +1560,7 @@ int render_impl(rt_ctx* c, const rt_render_params* p, bool pipelined) {
     // (small frames of small scenes: the two cross-stream dependencies cost more than the ~10 us of prep they hide)
     // (a frame that gets cuts always overlaps: the cut kernels are chains of dependent steps, ~0.3 ms of latency)
     const bool overlap = opt("RT_NO_PREP_OVERLAP") == nullptr &&  // (comparison knob, read per launch)
-                         (n_smp >= (size_t(1) << 24) || c->n_tris >= (1 << 18) || double(n_smp) >= cut_min_rays());
+                         (n_smp >= (size_t(1) << 24) || c->n_tris >= (1 << 18) || cut_mode(W, rows, spp) != 0);
     if (packet_launch) {
         c->cam_idx ^= 1;
         cs = &c->cam[c->cam_idx];
@@ -2167,7 +2189,7 @@ int rt_tile_cuts_host(const rt_scene* scene, const rt_render_params* p, int leve
         ca.tiles_x = cp.tiles_x[l];
         ca.n_tiles = (int32_t)cp.tiles[l];
         ca.cuts = cur.data();
-        ca.tris = (l == cp.lo && !opt("RT_NO_TRIM")) ? tris.data() : nullptr;
+        ca.tris = (l == cp.lo && !cp.single && !opt("RT_NO_TRIM")) ? tris.data() : nullptr;
         for (int64_t t = 0; t < cp.tiles[l]; ++t) {
             rtk::cut_refine(ca, (int)t, lists, 1);
             if (ca.tris) rtk::cut_trim(ca, (int)t, lists, 1);

@@ -153,6 +153,58 @@ def test_small_frames_get_no_cuts_by_default(ctx, monkeypatch):
     host.close()
 
 
+@pytest.mark.parametrize("name,coords,colors", list(scenes()), ids=[s[0] for s in scenes()])
+def test_single_level_cut_walk_equals_root_walk(ctx, monkeypatch, name, coords, colors):
+    """The one-level mode of mid-sized frames (RT_CUT1_MIN_RAYS=0: for every frame here), every scene, camera, tile
+    size and instantiation the full hierarchy is tested with."""
+    monkeypatch.delenv("RT_CUT_MIN_RAYS")
+    monkeypatch.setenv("RT_CUT1_MIN_RAYS", "0")
+    host = ra.HostScene(coords, colors, 0)
+    ctx.upload(host)
+    shapes = [(40, 56, 64), (37, 50, 50), (24, 33, 5), (21, 19, 1), (16, 24, 128), (30, 40, 100), (33, 47, 16), (90, 120, 3)]
+    for ci, ck in enumerate(CAMS + CAMS):
+        H, W, spp = shapes[(ci + (3 if name == "soup" else 0)) % len(shapes)]
+        cam = meshgen.camera_arrays(W, H, **ck)
+        both_ways(ctx, monkeypatch, cam, H, W, spp)
+        _, _, (lo, top) = ctx.last_cuts()
+        assert lo == top
+        both_ways(ctx, monkeypatch, cam, H, W, spp, rows=(8, H - 3))
+    host.close()
+
+
+def test_mid_sized_frames_get_one_short_cut_level_at_the_render_tile(ctx, monkeypatch):
+    """Frames of 2 M .. 12 M rays (the reference's own 400 x 225 x 50): ONE cut level, the render tile's blocks,
+    straight from the root, lists of at most 16 entries, no trimmed leaves -- and the same frame as the root walk."""
+    monkeypatch.delenv("RT_CUT_MIN_RAYS")
+    c0, k0 = meshgen.plate(24)
+    c1, k1 = meshgen.uv_sphere(10, 14, radius=0.8, center=(0.4, 0.3, -2.5))
+    host = ra.HostScene([c0, c1], [k0, k1], 0)
+    ctx.upload(host)
+    for (H, W, spp), ck in zip([(160, 200, 64), (150, 280, 50), (225, 400, 50)], CAMS):  # 2.05 M, 2.1 M, 4.5 M rays
+        cam = meshgen.camera_arrays(W, H, **ck)
+        a = both_ways(ctx, monkeypatch, cam, H, W, spp)
+        assert (a["hit_prim"] >= 0).any()
+        ctx.rng_seed(5489)
+        ctx.render(*cam, H, W, spp)
+        words, tx, (lo, top) = ctx.last_cuts()
+        assert lo == top and ctx.stats()["finest_cut_level"] == lo
+        assert words.shape[0] == tx * ((H + (1 << lo) - 1) >> lo) and tx == (W + (1 << lo) - 1) >> lo
+        valid = (words[:, 0] >> 31) == 1
+        assert valid.mean() > 0.9 and ((words[valid, 0] & 0xff) <= 16).all() and ((words[valid, 0] & 0xff) > 0).any()
+        assert not ((words[valid, 0] >> 16) & 1).any()  # CUT_SIMPLE is set by the trimming pass only
+        want, tx2, (lo2, top2) = ra.tile_cuts_host(host, *cam, H, W, spp, level=lo)
+        assert (tx, lo, top) == (tx2, lo2, top2) and np.array_equal(words[:, 0], want[:, 0])
+    # below 2 M rays: none; from 12 M rays: the whole hierarchy (several levels)
+    cam = meshgen.camera_arrays(200, 150)
+    ctx.render(*cam, 150, 200, 64)
+    assert ctx.last_cuts()[0].shape[0] == 0
+    monkeypatch.setenv("RT_CUT_MIN_RAYS", "0")
+    ctx.render(*cam, 150, 200, 64)
+    _, _, (lo, top) = ctx.last_cuts()
+    assert top > lo
+    host.close()
+
+
 def test_triangle_edges_on_block_corners_and_samples_on_edges(ctx, monkeypatch):
     """Adversarial for the trimmed leaves (cut_trim): a flat plate whose quad edges project EXACTLY onto pixel
     corners (every second one, so also onto the corners of the 2 x 2 blocks), a camera whose pixel grid is made of
