@@ -771,7 +771,7 @@ def main():
                        "hit_ids_written": want_ids, "frames_per_step_per_gpu": 1,
                        "cuts": ("off (RT_NO_CUT)" if os.environ.get("RT_NO_CUT") else
                                 "made per frame: the whole hierarchy for frames >= %g rays, one level at the render tile from %g rays"
-                                % (float(os.environ.get("RT_CUT_MIN_RAYS", 12e6)), float(os.environ.get("RT_CUT1_MIN_RAYS", 2e6)))),
+                                % (float(os.environ.get("RT_CUT_MIN_RAYS", 12e6)), float(os.environ.get("RT_CUT1_MIN_RAYS", 1e6)))),
                        "host_threads_per_rank": int(ra.lib.rt_host_threads()),
                        "parallelism": f"frame-sharded x{world}, no collective"},
             "roofline": roofline,

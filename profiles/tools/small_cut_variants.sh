@@ -1,6 +1,7 @@
 #!/bin/bash
-# Mid-sized frames (2 M .. 12 M rays): one cut level at the render tile (cut_mode 1) against no cuts, and its list
-# length, on the sphere bench (configs[1]) and the small-frame job.  Usage: bash profiles/tools/small_cut_variants.sh
+# Mid-sized frames (2 M .. 12 M rays): one cut level at the render tile (cut_mode 1) against no cuts, its list
+# length, with and without trimmed leaves, breadth-first kernel against the depth-first one, on the sphere bench
+# (configs[1]) and the small-frame job.  Usage: bash profiles/tools/small_cut_variants.sh
 cd "${GRAFT_REPO_ROOT:-.}"
 run() {
   echo "== $*"
@@ -10,9 +11,10 @@ d=json.loads(sys.stdin.read()); r=d['roofline']; print('sphere: step %.4f ms, ke
   env "$@" timeout -k 10 200 python3 profiles/tools/small_frames.py 2>&1 | sed -n 2p || exit 1
 }
 run RT_CUT1_MIN_RAYS=1e12
-run RT_CUT1_CAP=6
+run RT_CUT1_SERIAL=1
 run RT_CUT1_CAP=8
-run RT_CUT1_CAP=12
 run RT_CUT1_CAP=16
 run RT_CUT1_CAP=24
 run RT_CUT1_CAP=31
+run RT_CUT1_CAP=16 RT_NO_TRIM=1
+run RT_CUT1_CAP=31 RT_NO_TRIM=1

@@ -1,8 +1,9 @@
 #!/bin/bash
 # Kernel timeline of the last frames of the reference's own kind of job (one 2048-triangle mesh, 400x225, 50 spp,
-# 100 timesteps; the second, warm call of profiles/tools/cold_job.py).  Usage: bash profiles/tools/timeline_small.sh
+# 100 timesteps; the second, warm call of profiles/tools/cold_job.py).  Usage: bash profiles/tools/timeline_small.sh [ENV=VAL ...]
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
+for kv in "$@"; do export "$kv"; done
 rm -rf $R/gpurun_out/trace_small
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/trace_small -- python3 $R/profiles/tools/cold_job.py 100 32 > $R/gpurun_out/trace_small.log 2>&1 || { echo "trace failed"; tail -5 $R/gpurun_out/trace_small.log; exit 1; }
 grep "warm" $R/gpurun_out/trace_small.log

@@ -56,7 +56,7 @@ int fail(int code, const std::string& msg) {
 // -- by the first rt_create, or by the first host-only call that needs one -- and again only on rt_reload_options():
 // no render, upload or driver call reaches getenv.  opt("RT_X") returns the value taken then, or null when unset,
 // so each site keeps the meaning it had when it asked the environment itself.
-const char* const kOptionNames[] = {"RT_ADAPT_MIN_WORDS", "RT_ADAPT_RATIO", "RT_BUILD_AHEAD", "RT_BUILD_TIMING", "RT_COUNT_WITH_CUTS", "RT_CUT1_CAP", "RT_CUT1_MIN_RAYS", "RT_CUT_LO", "RT_CUT_MIN_RAYS", "RT_CUT_STEP", "RT_CUT_TOP", "RT_CUT_TOPCAP", "RT_DRIVER_TIMING", "RT_FORCE_PERLANE", "RT_INTERLEAVE", "RT_JITTER_SLOT_BYTES", "RT_JITTER_STREAMS", "RT_NO_ADAPT_STREAMS", "RT_NO_CUT", "RT_NO_FRAME_GROUPS", "RT_NO_INTERLEAVE", "RT_NO_LOOKAHEAD", "RT_NO_PAIR64", "RT_NO_PIPELINE", "RT_NO_PREP_OVERLAP", "RT_NO_SERIAL_TREES", "RT_NO_SMALL_TILES", "RT_NO_STATE_REUSE", "RT_NO_TRIM", "RT_PAD64_FROM", "RT_RNG_PRIO", "RT_STAGE_STREAMS", "RT_TILE_LOG2"};
+const char* const kOptionNames[] = {"RT_ADAPT_MIN_WORDS", "RT_ADAPT_RATIO", "RT_BUILD_AHEAD", "RT_BUILD_TIMING", "RT_COUNT_WITH_CUTS", "RT_CUT1_CAP", "RT_CUT1_MIN_RAYS", "RT_CUT1_SERIAL", "RT_CUT_LO", "RT_CUT_MIN_RAYS", "RT_CUT_STEP", "RT_CUT_TOP", "RT_CUT_TOPCAP", "RT_DRIVER_TIMING", "RT_FORCE_PERLANE", "RT_INTERLEAVE", "RT_JITTER_SLOT_BYTES", "RT_JITTER_STREAMS", "RT_NO_ADAPT_STREAMS", "RT_NO_CUT", "RT_NO_FRAME_GROUPS", "RT_NO_INTERLEAVE", "RT_NO_LOOKAHEAD", "RT_NO_PAIR64", "RT_NO_PIPELINE", "RT_NO_PREP_OVERLAP", "RT_NO_SERIAL_TREES", "RT_NO_SMALL_TILES", "RT_NO_STATE_REUSE", "RT_NO_TRIM", "RT_PAD64_FROM", "RT_RNG_PRIO", "RT_STAGE_STREAMS", "RT_TILE_LOG2"};
 constexpr int kNumOptions = (int)(sizeof(kOptionNames) / sizeof(kOptionNames[0]));
 struct OptionTable {
     std::mutex mu;
@@ -142,7 +142,7 @@ double cut_min_rays() {
 }
 double cut1_min_rays() {
     const char* mr = opt("RT_CUT1_MIN_RAYS");
-    return mr ? std::atof(mr) : 2e6;
+    return mr ? std::atof(mr) : 1e6;
 }
 int cut_mode(int W, int rows, int spp) {
     const double rays = double(W) * double(rows) * double(spp);
@@ -153,7 +153,7 @@ int cut_mode(int W, int rows, int spp) {
 // again, four times over, by their children), so they stop at half the room.
 int cut_cap(int l, const CutPlan& cp) {
     if (cp.single) {
-        const int cap1 = opt("RT_CUT1_CAP") ? std::atoi(opt("RT_CUT1_CAP")) : 16;  // (tuning knob)
+        const int cap1 = opt("RT_CUT1_CAP") ? std::atoi(opt("RT_CUT1_CAP")) : (int)rtk::CUT_CAP;  // (tuning knob)
         return std::max(1, std::min(cap1, (int)rtk::CUT_CAP));
     }
     const int top_cap = opt("RT_CUT_TOPCAP") ? std::atoi(opt("RT_CUT_TOPCAP")) : 15;  // (tuning knob)
@@ -1318,6 +1318,27 @@ int make_cuts(rt_ctx* c, hipStream_t st, const rt_render_params* p, int tile_log
     ca.parent = nullptr;
     ca.parent_tiles_x = 0;
     ca.mag = rtk::cut_magnitude(ca.fp, W, p->row_begin, rows);
+    if (cp.single && !opt("RT_CUT1_SERIAL")) {
+        // one level straight from the root, several lanes per block (cut_single_kernel)
+        const int l = cp.lo;
+        ca.lvl = l;
+        ca.parent_shift = 0;
+        ca.cap = cut_cap(l, cp);
+        ca.tiles_x = cp.tiles_x[l];
+        ca.n_tiles = (int32_t)cp.tiles[l];
+        ca.cuts = cuts + cp.offset_words[l];
+        ca.tris = opt("RT_NO_TRIM") ? nullptr : cam_tris;
+        constexpr int per_wave = 64 / rtk::CUT1_LANES;
+        hipLaunchKernelGGL(rtk::cut_single_kernel, dim3((unsigned)((cp.tiles[l] + per_wave - 1) / per_wave)), dim3(64), 0, st, ca);
+        HIP_TRY(hipGetLastError());
+        for (int q = cp.lo; q <= tile_log2 && q < rtk::CUT_MAX_LEVELS; ++q) {
+            out.lvl[q] = cuts + cp.offset_words[l];
+            out.tx[q] = cp.tiles_x[l];
+            out.eff[q] = l;
+        }
+        out.lo = cp.lo;
+        return RT_OK;
+    }
     int parent_lvl = -1;
     for (int l = cp.top; l >= cp.lo; --l) {  // each level from its parent's cuts, the top one from the root
         if (!cp.present[l]) continue;
@@ -2189,8 +2210,13 @@ int rt_tile_cuts_host(const rt_scene* scene, const rt_render_params* p, int leve
         ca.tiles_x = cp.tiles_x[l];
         ca.n_tiles = (int32_t)cp.tiles[l];
         ca.cuts = cur.data();
-        ca.tris = (l == cp.lo && !cp.single && !opt("RT_NO_TRIM")) ? tris.data() : nullptr;
+        const bool rounds = cp.single && !opt("RT_CUT1_SERIAL");  // (the breadth-first kernel's twin)
+        ca.tris = (l == cp.lo && (rounds || !cp.single) && !opt("RT_NO_TRIM")) ? tris.data() : nullptr;
         for (int64_t t = 0; t < cp.tiles[l]; ++t) {
+            if (rounds) {
+                rtk::cut_single_serial(ca, (int)t);
+                continue;
+            }
             rtk::cut_refine(ca, (int)t, lists, 1);
             if (ca.tris) rtk::cut_trim(ca, (int)t, lists, 1);
         }

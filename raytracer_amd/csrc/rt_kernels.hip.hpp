@@ -1340,6 +1340,333 @@ __global__ __launch_bounds__(CUT_THREADS) void cut_level_kernel(const CutArgs a)
     if (a.tris) cut_trim(a, tiy * a.tiles_x + tix, s_stk + threadIdx.x, CUT_THREADS);
 }
 
+// =======================================================================================
+// One level straight from the TLAS root with SEVERAL LANES PER BLOCK (cut_mode 1: frames of 2 M .. 12 M rays, e.g.
+// the reference's own 400 x 225 x 50).  cut_level_kernel gives a block one thread that walks depth first: ~100
+// dependent steps, and an image of 5 700 blocks is 90 waves on a GPU of 1 024 SIMDs -- 0.2 ms of latency for a
+// traversal of 0.1 ms.  Here a block's list is refined breadth first, one lane per entry: in every round each waiting
+// entry is classified (one node record, one box) and replaced IN PLACE -- by nothing (no ray of the block passes
+// it), by itself (final), or by its two children (waiting), the latter while the list has room, granted left to
+// right -- so the list stays in visit order and a round costs one step whatever the list's length: as many rounds
+// as the tree is deep.  Any list produced this way is a valid cut (every step is one of cut_refine's); which nodes
+// get refined when room runs out differs from the depth-first walk, so the host twin (cut_single_serial) follows
+// the same rounds.  The leaves are then trimmed like cut_trim does (one lane per entry tests its triangles, the list
+// is assembled in order by one lane).
+// =======================================================================================
+constexpr int CUT1_LANES = 32;  // lanes per block >= entries per list + 1
+static_assert(CUT1_LANES > CUT_CAP && 64 % CUT1_LANES == 0, "one lane per entry");
+
+struct Cut1Step {
+    int k;           // words this entry turns into: 0, 1 or 2 (two: only while the list has room, else `alone`)
+    uint32_t o[2];   // the words
+    bool fin[2];     // final (true) or waiting to be classified in the next round
+    uint32_t alone;  // k == 2 without room: this one word instead, final
+};
+
+// What one WAITING entry turns into (the cases of cut_refine's loop body, one to one).
+__host__ __device__ inline Cut1Step cut1_step(const CutArgs& a, const TileRays& tr, const uint32_t e) {
+    Cut1Step s;
+    s.k = 1;
+    s.o[0] = e;
+    s.o[1] = 0u;
+    s.fin[0] = s.fin[1] = true;
+    s.alone = e;
+    if (e & rt::DESC_LEAF) return s;  // (a leaf every ray passes: final)
+    const uint32_t kind = e & CUT_NODE;
+    if (kind == 0u) {  // an internal node every ray passes (e = index of its left child): its children, to be classified
+        s.k = 2;
+        s.o[0] = CUT_NODE | e;
+        s.o[1] = CUT_NODE | (e + 1u);
+        s.fin[0] = s.fin[1] = false;
+        return s;
+    }
+    const bool is_tlas = kind == rt::DESC_TLAS;
+    uint32_t idx = e & 0x1FFFFFFFu;
+    if (kind == rt::DESC_ROOT) idx = (uint32_t)a.slot_root[idx];
+    const rt::DevNode* const np = is_tlas ? a.tlas + (e & 0x3FFFFFFFu) : a.nodes + idx;
+    double mn[3], mx[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        mn[k] = np->mn[k];
+        mx[k] = np->mx[k];
+    }
+    const int32_t left = np->left, count = np->count, first = np->first;
+    const uint32_t desc = np->desc;
+    const int cls = cut_classify(mn, mx, tr);
+    if (cls == 0) {
+        s.k = 0;
+        return s;
+    }
+    if (is_tlas) {
+        // kept (tested per ray, as the reference does when it pops the node) unless every ray passes it
+        if (cls == 1 && left >= 0) {
+            s.k = 2;
+            s.o[0] = rt::DESC_TLAS | (uint32_t)left;
+            s.o[1] = rt::DESC_TLAS | (uint32_t)(left + 1);
+            s.fin[0] = s.fin[1] = false;
+        } else if (cls == 1 && left < 0 && count >= 1 && count <= 2) {
+            s.k = count;
+            for (int q = 0; q < count; ++q) {
+                s.o[q] = rt::DESC_ROOT | (uint32_t)(first + q);
+                s.fin[q] = false;
+            }
+        }
+        return s;
+    }
+    s.alone = (cls == 1) ? desc : (CUT_NODE | idx);
+    if (!(desc & rt::DESC_LEAF)) {  // internal: gives way to its children (its own test, sure or not, only prunes)
+        s.k = 2;
+        s.o[0] = CUT_NODE | desc;
+        s.o[1] = CUT_NODE | (desc + 1u);
+        s.fin[0] = s.fin[1] = false;
+    } else {
+        s.o[0] = s.alone;
+    }
+    return s;
+}
+
+// What cut_trim needs to know about one entry of a finished list: its leaf (0: not a trimmable leaf), whether the
+// leaf's box is tested per ray, and which of its triangles some ray of the block may hit.
+struct Cut1Leaf {
+    uint32_t leaf, live;
+    bool per_ray;
+};
+__host__ __device__ inline Cut1Leaf cut1_leaf(const CutArgs& a, const uint32_t e, const double (&dd)[4][3], const double slack) {
+    Cut1Leaf r;
+    r.leaf = 0u;
+    r.live = 0u;
+    r.per_ray = false;
+    if (e & rt::DESC_LEAF) {
+        r.leaf = e;
+    } else if ((e & CUT_NODE) == CUT_NODE) {
+        const uint32_t d = a.nodes[e & CUT_NODE_IDX].desc;
+        if (d & rt::DESC_LEAF) {
+            r.leaf = d;
+            r.per_ray = true;
+        }
+    }
+    const uint32_t cnt = ((r.leaf >> 28) & 7u) + 1u;
+    if (r.leaf == 0u || cnt == 8u) {  // not a leaf, or one with its range in leaf_ext: stays as it is
+        r.leaf = 0u;
+        return r;
+    }
+    r.live = cut_live_triangles(a.tris, r.leaf & rt::DESC_TRI_MASK, cnt, dd, slack);
+    return r;
+}
+
+// The trimmed list, in order, from the entries and what cut1_leaf found (element i at x[i * stride]); cut_trim's
+// rules word for word.  Returns the number of words written to out[1..]; *simple as cut_trim sets CUT_SIMPLE.
+__host__ __device__ inline int cut1_assemble(const int n, const uint32_t* ent, const uint32_t* leafs, const uint32_t* lives,
+                                             const uint32_t* per_ray, const int stride, uint32_t* const out, bool* simple_out) {
+    int w = 0;
+    bool simple = true;
+    for (int i = 0; i < n; ++i) {
+        const uint32_t e = ent[i * stride], leaf = leafs[i * stride], live = lives[i * stride];
+        const int rest = n - 1 - i;  // every later entry can do with one word
+        if (leaf == 0u) {
+            out[1 + w++] = e;
+            simple = false;
+            continue;
+        }
+        if (live == 0u) continue;
+        const uint32_t cnt = ((leaf >> 28) & 7u) + 1u;
+        const uint32_t first = leaf & rt::DESC_TRI_MASK;
+        int lo = 0, hi = (int)cnt - 1;
+        while (!((live >> lo) & 1u)) ++lo;
+        while (!((live >> hi) & 1u)) --hi;
+        const uint32_t range = rt::DESC_LEAF | ((uint32_t)(hi - lo) << 28) | (first + (uint32_t)lo);
+        if (per_ray[i * stride]) {
+            if (w + 2 + rest <= CUT_CAP) {
+                out[1 + w++] = e | CUT_TRIM;
+                out[1 + w++] = range;
+            } else {
+                out[1 + w++] = e;
+                simple = false;
+            }
+            continue;
+        }
+        int runs = 0;
+        for (int m = lo; m <= hi; ++m) runs += ((live >> m) & 1u) && !(m > lo && ((live >> (m - 1)) & 1u));
+        if (runs > 1 && w + runs + rest <= CUT_CAP) {
+            int m = lo;
+            while (m <= hi) {
+                if (!((live >> m) & 1u)) {
+                    ++m;
+                    continue;
+                }
+                int m1 = m;
+                while (m1 + 1 <= hi && ((live >> (m1 + 1)) & 1u)) ++m1;
+                out[1 + w++] = rt::DESC_LEAF | ((uint32_t)(m1 - m) << 28) | (first + (uint32_t)m);
+                m = m1 + 1;
+            }
+        } else {
+            out[1 + w++] = range;
+        }
+    }
+    *simple_out = simple;
+    return w;
+}
+
+// Whether a finished list of this block may be trimmed, and with which corner rays and slack (cut_trim's preamble).
+__host__ __device__ inline bool cut1_trim_setup(const CutArgs& a, const int tile, const TileRays& tr, double (&dd)[4][3],
+                                                double& slack) {
+    if (!a.tris) return false;
+    if (tr.kind[0] == 2 && tr.kind[1] == 2 && tr.kind[2] == 2) return false;  // no sign-keeping axis
+    cut_corner_rays(a, tile % a.tiles_x, tile / a.tiles_x, dd);
+    double ddmax = 0.0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        ddmax = __builtin_fmax(ddmax, (__builtin_fabs(dd[c][0]) + __builtin_fabs(dd[c][1])) + __builtin_fabs(dd[c][2]));
+    slack = 1e-9 * ddmax + 4.0 * (0x1p-50 * a.mag);
+    return slack < 1e100;
+}
+
+// Host twin of cut_single_kernel for one block: the same rounds, one entry after the other.
+__host__ __device__ inline void cut_single_serial(const CutArgs& a, const int tile) {
+    uint32_t* const out = a.cuts + (size_t)tile * CUT_WORDS;
+    TileRays tr;
+    if (!cut_tile_rays(a, tile % a.tiles_x, tile / a.tiles_x, tr)) {
+        out[0] = 0u;
+        return;
+    }
+    uint32_t ent[2][CUT_WORDS];
+    bool fin[2][CUT_WORDS];
+    int cur = 0, n = 1;
+    ent[0][0] = rt::DESC_TLAS;
+    fin[0][0] = false;
+    for (;;) {
+        bool waiting = false;
+        for (int i = 0; i < n; ++i) waiting = waiting || !fin[cur][i];
+        if (!waiting) break;
+        Cut1Step st[CUT_WORDS];
+        int total1 = 0;
+        for (int i = 0; i < n; ++i) {
+            if (fin[cur][i]) {
+                st[i].k = 1;
+                st[i].o[0] = ent[cur][i];
+                st[i].fin[0] = true;
+            } else {
+                st[i] = cut1_step(a, tr, ent[cur][i]);
+            }
+            total1 += st[i].k >= 1;
+        }
+        int extra = a.cap - total1, m = 0;
+        for (int i = 0; i < n; ++i) {
+            if (st[i].k == 2) {
+                if (extra > 0) {
+                    --extra;
+                } else {
+                    st[i].k = 1;
+                    st[i].o[0] = st[i].alone;
+                    st[i].fin[0] = true;
+                }
+            }
+            for (int q = 0; q < st[i].k; ++q) {
+                ent[cur ^ 1][m] = st[i].o[q];
+                fin[cur ^ 1][m] = st[i].fin[q];
+                ++m;
+            }
+        }
+        n = m;
+        cur ^= 1;
+    }
+    uint32_t hdr = CUT_VALID | ((uint32_t)tr.kind[0] << 8) | ((uint32_t)tr.kind[1] << 10) | ((uint32_t)tr.kind[2] << 12);
+    double dd[4][3], slack = 0.0;
+    if (cut1_trim_setup(a, tile, tr, dd, slack)) {
+        uint32_t leafs[CUT_WORDS], lives[CUT_WORDS], per_ray[CUT_WORDS];
+        for (int i = 0; i < n; ++i) {
+            const Cut1Leaf r = cut1_leaf(a, ent[cur][i], dd, slack);
+            leafs[i] = r.leaf;
+            lives[i] = r.live;
+            per_ray[i] = r.per_ray ? 1u : 0u;
+        }
+        bool simple = false;
+        const int w = cut1_assemble(n, ent[cur], leafs, lives, per_ray, 1, out, &simple);
+        out[0] = hdr | (uint32_t)w | (simple ? CUT_SIMPLE : 0u);
+    } else {
+        for (int i = 0; i < n; ++i) out[1 + i] = ent[cur][i];
+        out[0] = hdr | (uint32_t)n;
+    }
+}
+
+// 64 / CUT1_LANES blocks per wave, one lane per entry of a block's list.
+__global__ __launch_bounds__(64) void cut_single_kernel(const CutArgs a) {
+    constexpr int G = 64 / CUT1_LANES;
+    __shared__ uint32_t s_ent[2][G][CUT_WORDS];
+    __shared__ uint32_t s_fin[2][G][CUT_WORDS];
+    __shared__ uint32_t s_leaf[G][CUT_WORDS], s_live[G][CUT_WORDS], s_pr[G][CUT_WORDS];
+    const int lane = threadIdx.x & 63;
+    const int g = lane / CUT1_LANES, l = lane % CUT1_LANES;
+    const int tile_raw = (int)blockIdx.x * G + g;
+    const bool have = tile_raw < a.n_tiles;
+    const int tile = have ? tile_raw : a.n_tiles - 1;  // (lanes without a block follow the last one and write nothing)
+    uint32_t* const out = a.cuts + (size_t)tile * CUT_WORDS;
+    TileRays tr;
+    const bool ok = cut_tile_rays(a, tile % a.tiles_x, tile / a.tiles_x, tr);
+    const unsigned long long gbits = (CUT1_LANES == 64) ? ~0ull : (((1ull << CUT1_LANES) - 1ull) << (g * CUT1_LANES));
+    const unsigned long long below = gbits & ((1ull << lane) - 1ull);
+    int cur = 0, n = ok ? 1 : 0;
+    if (l == 0) {
+        s_ent[0][g][0] = rt::DESC_TLAS;
+        s_fin[0][g][0] = 0u;
+    }
+    __syncthreads();
+    for (;;) {
+        const bool mine = l < n;
+        const uint32_t e = mine ? s_ent[cur][g][l] : 0u;
+        const bool f = mine ? (s_fin[cur][g][l] != 0u) : true;
+        if (__builtin_amdgcn_ballot_w64(mine && !f) == 0ull) break;
+        Cut1Step st;
+        st.k = mine ? 1 : 0;
+        st.o[0] = e;
+        st.o[1] = 0u;
+        st.fin[0] = st.fin[1] = true;
+        st.alone = e;
+        if (mine && !f) st = cut1_step(a, tr, e);
+        const unsigned long long b1 = __builtin_amdgcn_ballot_w64(st.k >= 1) & gbits;
+        const unsigned long long b2 = __builtin_amdgcn_ballot_w64(st.k == 2) & gbits;
+        const int extra = a.cap - __builtin_popcountll(b1);
+        const bool granted = st.k == 2 && __builtin_popcountll(b2 & below) < extra;
+        if (st.k == 2 && !granted) {
+            st.k = 1;
+            st.o[0] = st.alone;
+            st.fin[0] = true;
+        }
+        const unsigned long long bg = __builtin_amdgcn_ballot_w64(granted) & gbits;
+        const int off = __builtin_popcountll(b1 & below) + __builtin_popcountll(bg & below);
+        for (int q = 0; q < st.k; ++q) {
+            s_ent[cur ^ 1][g][off + q] = st.o[q];
+            s_fin[cur ^ 1][g][off + q] = st.fin[q] ? 1u : 0u;
+        }
+        n = __builtin_popcountll(b1) + __builtin_popcountll(bg);
+        cur ^= 1;
+        __syncthreads();
+    }
+    const uint32_t hdr = CUT_VALID | ((uint32_t)tr.kind[0] << 8) | ((uint32_t)tr.kind[1] << 10) | ((uint32_t)tr.kind[2] << 12);
+    double dd[4][3], slack = 0.0;
+    const bool trim = ok && cut1_trim_setup(a, tile, tr, dd, slack);  // (the same for every lane of a block)
+    if (trim && l < n) {
+        const Cut1Leaf r = cut1_leaf(a, s_ent[cur][g][l], dd, slack);
+        s_leaf[g][l] = r.leaf;
+        s_live[g][l] = r.live;
+        s_pr[g][l] = r.per_ray ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!have) return;
+    if (!ok) {
+        if (l == 0) out[0] = 0u;
+    } else if (trim) {
+        if (l == 0) {
+            bool simple = false;
+            const int w = cut1_assemble(n, s_ent[cur][g], s_leaf[g], s_live[g], s_pr[g], 1, out, &simple);
+            out[0] = hdr | (uint32_t)w | (simple ? CUT_SIMPLE : 0u);
+        }
+    } else {
+        if (l < n) out[1 + l] = s_ent[cur][g][l];
+        if (l == 0) out[0] = hdr | (uint32_t)n;
+    }
+}
+
 // ---- the render kernels' side of the cuts (shared by the f64 and the fp32 packet kernels) ----
 // The cut of the smallest aligned pixel block that holds a batch's pixels: m_first / m_last are the Morton indices
 // (within the tile) of its first and last ray's pixel -- an aligned block is an interval of Morton indices -- and
