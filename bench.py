@@ -91,6 +91,11 @@ def workload(name):
         H = W = 2048
         spp = 50
         label = "1,048,352-triangle deformed plate (1 BLAS), 2048x2048, 50 spp"
+    elif name == "plate32k":  # (experiments: a mid-sized mesh, the multi-frame job's unit)
+        c, k = meshgen.plate(128, side=5.0, x0=-2.5, y0=-2.5, z0=-4.0)
+        coords, colors = [c], [k]
+        H, W, spp = 576, 1024, 50
+        label = "32,768-triangle deformed plate (1 BLAS), 1024x576, 50 spp"
     elif name == "sphere":
         # BASELINE.json configs[1]: the reference's sphere_gmsh_vtk_test_2d_manyelems.vtk (data fixture),
         # 1 camera, 50-sample anti-aliasing, 1 frame, at the reference's 400x225 (rttests.py:31-33)
@@ -114,6 +119,9 @@ def workload(name):
     if os.environ.get("RT_BENCH_SPP"):  # experiments only: the same scene at another sample count
         spp = int(os.environ["RT_BENCH_SPP"])
         label += f" [RT_BENCH_SPP={spp}]"
+    if os.environ.get("RT_BENCH_SIZE"):  # experiments only: WxH
+        W, H = (int(v) for v in os.environ["RT_BENCH_SIZE"].lower().split("x"))
+        label += f" [RT_BENCH_SIZE={W}x{H}]"
     cam = meshgen.camera_arrays(W, H)
     return label, coords, colors, cam, H, W, spp
 

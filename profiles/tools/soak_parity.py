@@ -4,7 +4,8 @@ shapes, row bands and sample counts on both sides of every instantiation boundar
 C ABI with per-sample outputs and compared with the oracle BIT FOR BIT (hit ids, t, intensity, rgb), plus, for a
 third of the cases, the hit ids against the treeless argmin over all triangles.  The oracle is the checker here
 (test infrastructure); nothing of it is timed.  Frames this small are walked from the root by default:
-RT_CUT_MIN_RAYS=0 in the environment makes every frame take the cut walk (the path of the large frames).
+RT_CUT_MIN_RAYS=0 in the environment makes every frame take the cut walk (the path of the large frames),
+RT_CUT1_MIN_RAYS=0 RT_CUT1_MAX_TRIS_PER_BLOCK=1e9 the one-level cuts of mid-sized frames (cut_single_kernel).
 Usage: [RT_CUT_MIN_RAYS=0] python profiles/tools/soak_parity.py [cases] [first_seed]"""
 import os
 import sys

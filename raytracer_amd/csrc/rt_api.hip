@@ -56,7 +56,7 @@ int fail(int code, const std::string& msg) {
 // -- by the first rt_create, or by the first host-only call that needs one -- and again only on rt_reload_options():
 // no render, upload or driver call reaches getenv.  opt("RT_X") returns the value taken then, or null when unset,
 // so each site keeps the meaning it had when it asked the environment itself.
-const char* const kOptionNames[] = {"RT_ADAPT_MIN_WORDS", "RT_ADAPT_RATIO", "RT_BUILD_AHEAD", "RT_BUILD_TIMING", "RT_COUNT_WITH_CUTS", "RT_CUT1_CAP", "RT_CUT1_MIN_RAYS", "RT_CUT1_SERIAL", "RT_CUT_LO", "RT_CUT_MIN_RAYS", "RT_CUT_STEP", "RT_CUT_TOP", "RT_CUT_TOPCAP", "RT_DRIVER_TIMING", "RT_FORCE_PERLANE", "RT_INTERLEAVE", "RT_JITTER_SLOT_BYTES", "RT_JITTER_STREAMS", "RT_NO_ADAPT_STREAMS", "RT_NO_CUT", "RT_NO_FRAME_GROUPS", "RT_NO_INTERLEAVE", "RT_NO_LOOKAHEAD", "RT_NO_PAIR64", "RT_NO_PIPELINE", "RT_NO_PREP_OVERLAP", "RT_NO_SERIAL_TREES", "RT_NO_SMALL_TILES", "RT_NO_STATE_REUSE", "RT_NO_TRIM", "RT_PAD64_FROM", "RT_RNG_PRIO", "RT_STAGE_STREAMS", "RT_TILE_LOG2"};
+const char* const kOptionNames[] = {"RT_ADAPT_MIN_WORDS", "RT_ADAPT_RATIO", "RT_BUILD_AHEAD", "RT_BUILD_TIMING", "RT_COUNT_WITH_CUTS", "RT_CUT1_CAP", "RT_CUT1_MAX_TRIS_PER_BLOCK", "RT_CUT1_MIN_RAYS", "RT_CUT1_SERIAL", "RT_CUT_LO", "RT_CUT_MIN_RAYS", "RT_CUT_STEP", "RT_CUT_TOP", "RT_CUT_TOPCAP", "RT_DRIVER_TIMING", "RT_FORCE_PERLANE", "RT_INTERLEAVE", "RT_JITTER_SLOT_BYTES", "RT_JITTER_STREAMS", "RT_NO_ADAPT_STREAMS", "RT_NO_CUT", "RT_NO_FRAME_GROUPS", "RT_NO_INTERLEAVE", "RT_NO_LOOKAHEAD", "RT_NO_PAIR64", "RT_NO_PIPELINE", "RT_NO_PREP_OVERLAP", "RT_NO_SERIAL_TREES", "RT_NO_SMALL_TILES", "RT_NO_STATE_REUSE", "RT_NO_TRIM", "RT_PAD64_FROM", "RT_RNG_PRIO", "RT_STAGE_STREAMS", "RT_TILE_LOG2"};
 constexpr int kNumOptions = (int)(sizeof(kOptionNames) / sizeof(kOptionNames[0]));
 struct OptionTable {
     std::mutex mu;
@@ -130,12 +130,15 @@ struct CutPlan {
     bool single = false;  // cut_mode 1: one level, the render tile's
 };
 
-// How a frame's walk starts, by its number of rays (RT_CUT_MIN_RAYS, RT_CUT1_MIN_RAYS: tuning knobs):
-//   2  the whole hierarchy of cuts down to the finest level a batch can ask for, leaves trimmed (>= 12 M rays);
-//   1  ONE level, the render tile's blocks, straight from the root, untrimmed and with short lists: the cut kernel is
-//      a chain of dependent steps however small the image, and for a 400 x 225 x 50 frame (4.5 M rays) every further
-//      launch and every further refinement step costs more than it takes off the traversal;
-//   0  every batch walks from the root (< 2 M rays).
+// How a frame's walk starts (RT_CUT_MIN_RAYS, RT_CUT1_MIN_RAYS, RT_CUT1_MAX_TRIS_PER_BLOCK: tuning knobs):
+//   2  the whole hierarchy of cuts down to the finest level a batch can ask for, leaves trimmed: frames of >= 12 M
+//      rays (its kernels give a block one thread that walks depth first: they need many blocks to fill the GPU);
+//   1  ONE level, the render tile's blocks, straight from the root, made breadth first with one lane per list entry
+//      (cut_single_kernel): frames of 1 M .. 12 M rays -- the reference's own 400 x 225 x 50 -- of scenes with at
+//      most 8 triangles per block.  A list of <= 31 entries pays when it reaches the leaves; over a block that
+//      holds hundreds of triangles it is 31 internal nodes, each a per-ray test with its dispatch, and loses
+//      3-10 % against the root walk (profiles/r03f/cut_policy_sweep.txt);
+//   0  every batch walks from the root.
 double cut_min_rays() {
     const char* mr = opt("RT_CUT_MIN_RAYS");
     return mr ? std::atof(mr) : 12e6;
@@ -144,9 +147,15 @@ double cut1_min_rays() {
     const char* mr = opt("RT_CUT1_MIN_RAYS");
     return mr ? std::atof(mr) : 1e6;
 }
-int cut_mode(int W, int rows, int spp) {
+int cut_mode(int W, int rows, int spp, int tile_log2, int64_t n_tris) {
     const double rays = double(W) * double(rows) * double(spp);
-    return rays >= cut_min_rays() ? 2 : (rays >= cut1_min_rays() ? 1 : 0);
+    if (rays >= cut_min_rays()) return 2;
+    if (rays < cut1_min_rays()) return 0;
+    const int ts = 1 << tile_log2;
+    const double blocks = double((W + ts - 1) / ts) * double((rows + ts - 1) / ts);
+    const char* mt = opt("RT_CUT1_MAX_TRIS_PER_BLOCK");
+    const double per_block = mt ? std::atof(mt) : 8.0;
+    return double(n_tris) <= per_block * blocks ? 1 : 0;
 }
 
 // Entries a list of level l may hold: coarse levels only hand a starting point down (their blocks are refined
@@ -160,7 +169,7 @@ int cut_cap(int l, const CutPlan& cp) {
     return (l > cp.lo + 1) ? std::max(1, std::min(top_cap, (int)rtk::CUT_CAP)) : (int)rtk::CUT_CAP;
 }
 
-CutPlan plan_cuts(int W, int rows, int spp, int tile_log2) {
+CutPlan plan_cuts(int W, int rows, int spp, int tile_log2, int64_t n_tris) {
     CutPlan cp;
     // a batch holds the rays of ceil(64 / spp) pixels or more: the smallest aligned block it can lie in
     const int pix = (64 + spp - 1) / spp;
@@ -177,7 +186,7 @@ CutPlan plan_cuts(int W, int rows, int spp, int tile_log2) {
     // (tuning knob; never below the render tile's level: a batch looks its cut up at levels lo..tile_log2 and takes
     // the next coarser level that was made, which must exist)
     if (const char* e = opt("RT_CUT_TOP")) cp.top = std::max({cp.lo, tile_log2, std::atoi(e)});
-    if (cut_mode(W, rows, spp) == 1) {
+    if (cut_mode(W, rows, spp, tile_log2, n_tris) == 1) {
         cp.single = true;
         cp.lo = cp.top = tile_log2;
     }
@@ -1305,8 +1314,8 @@ int make_cuts(rt_ctx* c, hipStream_t st, const rt_render_params* p, int tile_log
     // The cut kernels are chains of dependent steps (~0.3 ms however small the image) and save a third to a half of
     // the traversal.  Measured: 2048^2 x 4 spp (16.7 M rays, 1 M triangles) 1.47 -> 1.32 ms per frame with cuts,
     // 400 x 225 x 50 spp (4.5 M rays) 0.30 -> 0.49 ms.
-    if (!cuts || !allowed || no_cut || cut_mode(W, rows, spp) == 0) return RT_OK;
-    const CutPlan cp = plan_cuts(W, rows, spp, tile_log2);
+    if (!cuts || !allowed || no_cut || cut_mode(W, rows, spp, tile_log2, c->n_tris) == 0) return RT_OK;
+    const CutPlan cp = plan_cuts(W, rows, spp, tile_log2, c->n_tris);
     rtk::CutArgs ca;
     ca.nodes = cam_nodes;
     ca.tlas = cam_tlas;
@@ -1581,14 +1590,14 @@ int render_impl(rt_ctx* c, const rt_render_params* p, bool pipelined) {
     // (small frames of small scenes: the two cross-stream dependencies cost more than the ~10 us of prep they hide)
     // (a frame that gets cuts always overlaps: the cut kernels are chains of dependent steps, ~0.3 ms of latency)
     const bool overlap = opt("RT_NO_PREP_OVERLAP") == nullptr &&  // (comparison knob, read per launch)
-                         (n_smp >= (size_t(1) << 24) || c->n_tris >= (1 << 18) || cut_mode(W, rows, spp) != 0);
+                         (n_smp >= (size_t(1) << 24) || c->n_tris >= (1 << 18) || cut_mode(W, rows, spp, tile_log2, c->n_tris) != 0);
     if (packet_launch) {
         c->cam_idx ^= 1;
         cs = &c->cam[c->cam_idx];
         if ((rc = cs->nodes.ensure(c->n_nodes))) return rc;
         if ((rc = cs->tlas.ensure(c->n_tlas))) return rc;
         if ((rc = cs->tris.ensure((size_t)c->n_tris))) return rc;
-        cp = plan_cuts(W, rows, spp, tile_log2);
+        cp = plan_cuts(W, rows, spp, tile_log2, c->n_tris);
         if (cp.tiles[cp.lo] > 0x7fffffff) return fail(RT_E_LIMIT, "rt_render: too many pixel blocks");
         if ((rc = cs->cuts.ensure(size_t(cp.total_words)))) return rc;
         pb.cam_nodes = cs->nodes.p;
@@ -1731,7 +1740,7 @@ int render_impl(rt_ctx* c, const rt_render_params* p, bool pipelined) {
         CutTables ct;
         {
             // (all on c->stream, in the set of the last launch: ordered behind that launch's kernel)
-            cp = plan_cuts(W, rows, spp, tile_log2);
+            cp = plan_cuts(W, rows, spp, tile_log2, c->n_tris);
             cs = &c->cam[c->cam_idx];
             if ((rc = cs->nodes.ensure(c->n_nodes))) return rc;
             if ((rc = cs->tlas.ensure(c->n_tlas))) return rc;
@@ -2073,7 +2082,7 @@ int rt_render_static(rt_ctx* c, const rt_render_params* p, const double* d_jitte
     pb.hit_t = nullptr;
     pb.counters = count ? reinterpret_cast<unsigned long long*>(ptr) : nullptr;
     // tile cuts only speed the walk up (same results without): used when the image's tiles fit the array too
-    pb.cuts = (off_cuts + size_t(plan_cuts(W, rows, spp, tile_log2).total_words) * sizeof(uint32_t) <=
+    pb.cuts = (off_cuts + size_t(plan_cuts(W, rows, spp, tile_log2, c->n_tris).total_words) * sizeof(uint32_t) <=
                size_t(RT_STATIC_SCRATCH_BYTES))
                   ? reinterpret_cast<uint32_t*>(ptr + off_cuts)
                   : nullptr;
@@ -2146,7 +2155,7 @@ int rt_tile_cuts_host(const rt_scene* scene, const rt_render_params* p, int leve
     const int W = p->image_width, spp = p->samples, rows = p->row_end - p->row_begin;
     if (W < 1 || spp < 1 || rows < 1) return fail(RT_E_INVALID, "rt_tile_cuts_host: bad image");
     const int tile_log2 = pick_tile_log2(true, spp, W, rows);
-    const CutPlan cp = plan_cuts(W, rows, spp, tile_log2);
+    const CutPlan cp = plan_cuts(W, rows, spp, tile_log2, (int64_t)s.prim_mesh.size());
     if (level_lo) *level_lo = cp.lo;
     if (level_top) *level_top = cp.top;
     if (level < cp.lo || level > cp.top || !cp.present[level]) return fail(RT_E_INVALID, "rt_tile_cuts_host: no such level");

@@ -159,6 +159,7 @@ def test_single_level_cut_walk_equals_root_walk(ctx, monkeypatch, name, coords, 
     size and instantiation the full hierarchy is tested with."""
     monkeypatch.delenv("RT_CUT_MIN_RAYS")
     monkeypatch.setenv("RT_CUT1_MIN_RAYS", "0")
+    monkeypatch.setenv("RT_CUT1_MAX_TRIS_PER_BLOCK", "1e9")  # (these images are a few hundred blocks)
     host = ra.HostScene(coords, colors, 0)
     ctx.upload(host)
     shapes = [(40, 56, 64), (37, 50, 50), (24, 33, 5), (21, 19, 1), (16, 24, 128), (30, 40, 100), (33, 47, 16), (90, 120, 3)]
@@ -198,10 +199,16 @@ def test_mid_sized_frames_get_one_short_cut_level_at_the_render_tile(ctx, monkey
         n = words[:, 0] & 0xff
         live = np.arange(31)[None, :] < np.where(valid, n, 0)[:, None]
         assert np.array_equal(words[:, 1:][live], want[:, 1:][live])
-    # below 1 M rays: none; from 12 M rays: the whole hierarchy (several levels)
+    # below 1 M rays: none; more than 8 triangles per block: none; from 12 M rays: the whole hierarchy (several levels)
     cam = meshgen.camera_arrays(200, 150)
     ctx.render(*cam, 150, 200, 32)
     assert ctx.last_cuts()[0].shape[0] == 0
+    monkeypatch.setenv("RT_CUT1_MAX_TRIS_PER_BLOCK", "0.5")
+    ctx.render(*cam, 150, 200, 64)
+    assert ctx.last_cuts()[0].shape[0] == 0
+    monkeypatch.delenv("RT_CUT1_MAX_TRIS_PER_BLOCK")
+    ctx.render(*cam, 150, 200, 64)
+    assert ctx.last_cuts()[0].shape[0] > 0
     monkeypatch.setenv("RT_CUT_MIN_RAYS", "0")
     ctx.render(*cam, 150, 200, 64)
     _, _, (lo, top) = ctx.last_cuts()
