@@ -9,12 +9,15 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <deque>
+#include <functional>
 #include <future>
 #include <map>
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rtgpu.h"
@@ -724,6 +727,63 @@ int ensure_staged_pool(rt_ctx* c, size_t n) {
 
 std::mutex g_global_mu;
 rt_ctx* g_global_ctx[64] = {};
+
+// A few persistent helper threads for the frame driver (one build per timestep, one file per frame): starting a
+// thread per task (std::async) is 30-50 us each, twice per frame -- most of the host's time per frame of a job of
+// small frames.  Tasks run in submission order; the threads live until the process ends.
+class TaskThreads {
+public:
+    explicit TaskThreads(int n) {
+        for (int i = 0; i < n; ++i)
+            threads_.emplace_back([this] {
+                for (;;) {
+                    std::function<void()> job;
+                    {
+                        std::unique_lock<std::mutex> lk(mu_);
+                        cv_.wait(lk, [&] { return stop_ || !queue_.empty(); });
+                        if (queue_.empty()) return;  // (stop_)
+                        job = std::move(queue_.front());
+                        queue_.pop_front();
+                    }
+                    job();
+                }
+            });
+    }
+    ~TaskThreads() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto& t : threads_) t.join();
+    }
+    template <class F>
+    auto submit(F f) -> std::future<decltype(f())> {
+        auto task = std::make_shared<std::packaged_task<decltype(f())()>>(std::move(f));
+        auto fut = task->get_future();
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            queue_.emplace_back([task] { (*task)(); });
+        }
+        cv_.notify_one();
+        return fut;
+    }
+
+private:
+    std::vector<std::thread> threads_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::deque<std::function<void()>> queue_;
+    bool stop_ = false;
+};
+TaskThreads& build_threads() {
+    static TaskThreads t(8);
+    return t;
+}
+TaskThreads& writer_thread() {
+    static TaskThreads t(1);
+    return t;
+}
 
 // Device address of `scratch` on each GPU (every GPU holds its own copy of the array at its own address).
 constexpr int kMaxDevices = 64;
@@ -2418,7 +2478,7 @@ int rt_render_scene(int image_height, int image_width, int number_of_samples, co
     const bool serial_trees = int64_t(n_meshes) * int64_t(depth) >= int64_t(rt::host_threads()) && !opt("RT_NO_SERIAL_TREES");
     auto build_async = [&](int t) {
         const int64_t ticket = rt::draw_build_ticket();  // (drawn here, in timestep order: the pool serves the oldest build first)
-        return std::async(std::launch::async, [=]() {
+        return build_threads().submit([=]() {
             Built b;
             const rt::AdoptBuildTicket adopt(ticket);
             try {
@@ -2546,7 +2606,7 @@ int rt_render_scene(int image_height, int image_width, int number_of_samples, co
         };
         auto write_async = [&](const std::string& path, uint8_t* src) {
             // like the reference, an unopenable file is reported and the job goes on
-            writer = std::async(std::launch::async, [path, image_width, image_height, src]() {
+            writer = writer_thread().submit([path, image_width, image_height, src]() {
                 (void)rt_write_ppm(path.c_str(), image_width, image_height, src);
             });
             wbuf ^= 1;
