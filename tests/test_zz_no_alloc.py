@@ -173,6 +173,28 @@ def test_static_entry_point_with_cuts_in_the_scratch_array_and_without_room_for_
         ctx.close()
 
 
+def test_static_entry_point_with_the_one_level_cuts_of_mid_sized_frames(monkeypatch):
+    """Frames of 1 M .. 12 M rays get one cut level made by cut_single_kernel (several lanes per block, static LDS
+    only): through the allocation-free entry point too, with the level carved out of the scratch array.  Here the
+    thresholds are the library's own (tests/conftest.py forces the whole hierarchy otherwise): 150 x 240 x 50 spp =
+    1.8 M rays, then a smaller image in the same mode."""
+    monkeypatch.delenv("RT_CUT_MIN_RAYS")
+    ctx = ra.Context(0)
+    hip = Hip()
+    try:
+        want, got = _case(ctx, hip, 40, 150, 240, 50, seed=31, counters=False)
+        _same(want, got, counters=False)
+        assert got["cut_level"] >= 0 and want["cut_level"] == got["cut_level"]
+        hip.release()
+        monkeypatch.setenv("RT_CUT1_MIN_RAYS", "0")
+        want, got = _case(ctx, hip, 24, 60, 90, 64, seed=32, counters=False)
+        _same(want, got, counters=False)
+        assert got["cut_level"] >= 0
+    finally:
+        hip.release()
+        ctx.close()
+
+
 def test_static_entry_point_refuses_a_second_context_while_the_first_ones_launch_runs():
     """All contexts on a GPU share that GPU's scratch array: a call from another context while a launch into the
     array has not finished returns RT_E_BUSY and launches nothing; after rt_sync of the first context it goes through."""
