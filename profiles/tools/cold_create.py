@@ -1,6 +1,6 @@
 import sys, time
 t00 = time.perf_counter()
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "..", ".."))
 from raytracer_amd import _lib as L
 t0 = time.perf_counter()
 n = L.lib.rt_device_count()

@@ -1,5 +1,5 @@
 import sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "..", ".."))
 import numpy as np, raytracer_amd as ra
 from raytracer_amd import meshgen
 c, k = meshgen.plate(128, side=5.0, x0=-2.5, y0=-2.5, z0=-6.0)

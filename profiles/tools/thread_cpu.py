@@ -1,6 +1,6 @@
 """Per-thread CPU time of the multi-frame job (reads /proc/self/task after the run)."""
 import os, sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "..", ".."))
 import bench, raytracer_amd as ra
 def snap():
     out = {}
