@@ -59,7 +59,7 @@ int fail(int code, const std::string& msg) {
 // -- by the first rt_create, or by the first host-only call that needs one -- and again only on rt_reload_options():
 // no render, upload or driver call reaches getenv.  opt("RT_X") returns the value taken then, or null when unset,
 // so each site keeps the meaning it had when it asked the environment itself.
-const char* const kOptionNames[] = {"RT_ADAPT_MIN_WORDS", "RT_ADAPT_RATIO", "RT_BUILD_AHEAD", "RT_BUILD_TIMING", "RT_COUNT_WITH_CUTS", "RT_CUT1_CAP", "RT_CUT1_MAX_TRIS_PER_BLOCK", "RT_CUT1_MIN_RAYS", "RT_CUT1_SERIAL", "RT_CUT_LO", "RT_CUT_MIN_RAYS", "RT_CUT_STEP", "RT_CUT_TOP", "RT_CUT_TOPCAP", "RT_DRIVER_TIMING", "RT_FORCE_PERLANE", "RT_INTERLEAVE", "RT_JITTER_SLOT_BYTES", "RT_JITTER_STREAMS", "RT_NO_ADAPT_STREAMS", "RT_NO_CUT", "RT_NO_FRAME_GROUPS", "RT_NO_INTERLEAVE", "RT_NO_LOOKAHEAD", "RT_NO_PAIR64", "RT_NO_PIPELINE", "RT_NO_PREP_OVERLAP", "RT_NO_SERIAL_TREES", "RT_NO_SMALL_TILES", "RT_NO_STATE_REUSE", "RT_NO_TRIM", "RT_PAD64_FROM", "RT_RNG_PRIO", "RT_STAGE_STREAMS", "RT_TILE_LOG2"};
+const char* const kOptionNames[] = {"RT_ADAPT_MIN_WORDS", "RT_ADAPT_RATIO", "RT_BUILD_AHEAD", "RT_BUILD_TIMING", "RT_COUNT_WITH_CUTS", "RT_CUT1_CAP", "RT_CUT1_MAX_TRIS_PER_BLOCK", "RT_CUT1_MIN_RAYS", "RT_CUT1_SERIAL", "RT_CUT_LO", "RT_CUT_MIN_RAYS", "RT_CUT_STEP", "RT_CUT_TOP", "RT_CUT_TOPCAP", "RT_DRIVER_TIMING", "RT_FORCE_PERLANE", "RT_FRAMES_AHEAD", "RT_INTERLEAVE", "RT_JITTER_SLOT_BYTES", "RT_JITTER_STREAMS", "RT_NO_ADAPT_STREAMS", "RT_NO_CUT", "RT_NO_FRAME_GROUPS", "RT_NO_INTERLEAVE", "RT_NO_LOOKAHEAD", "RT_NO_PAIR64", "RT_NO_PIPELINE", "RT_NO_PREP_OVERLAP", "RT_NO_SERIAL_TREES", "RT_NO_SMALL_TILES", "RT_NO_STATE_REUSE", "RT_NO_TRIM", "RT_PAD64_FROM", "RT_RNG_PRIO", "RT_STAGE_STREAMS", "RT_TILE_LOG2"};
 constexpr int kNumOptions = (int)(sizeof(kOptionNames) / sizeof(kOptionNames[0]));
 struct OptionTable {
     std::mutex mu;
@@ -257,12 +257,13 @@ struct rt_ctx {
     // cut kernels.  Two sets used alternately: the prep + cut kernels of a launch run on prep_stream into the set
     // the PREVIOUS launch is not reading, so they overlap that launch's traversal kernel (they are chains of short,
     // latency-bound launches; the traversal is VALU-bound).  `ready`: the set's prep + cut kernels (prep_stream);
-    // `read_done`: the traversal kernel that last read it (c->stream).
+    // `read_seq`: the launch whose traversal kernel read it last (done_event_for finds the event that covers it).
     struct CamSet {
         DevBuf<rt::DevNode> nodes, tlas;
         DevBuf<rtk::CamTri> tris;
         DevBuf<uint32_t> cuts;  // per-block entry lists (cut_level_kernel)
-        hipEvent_t ready = nullptr, read_done = nullptr;
+        hipEvent_t ready = nullptr;
+        uint64_t read_seq = 0;  // the launch whose traversal kernel read the set last
         bool read_pending = false;
     } cam[2];
     int cam_idx = 0;                    // set of the last launch
@@ -280,9 +281,11 @@ struct rt_ctx {
     int fp_idx = 0;
     // rt_render_scene's pipelined launches: frame q+1 is enqueued before frame q is read back, so the
     // frame buffers alternate (intensity/rgb always hold the LAST launch's output, prev_* the one before)
-    DevBuf<double> prev_intensity;
-    DevBuf<uint8_t> prev_rgb;
-    hipEvent_t out_done = nullptr, prev_out_done = nullptr;  // traversal kernel of the last / previous launch
+    DevBuf<double> prev_intensity, prev2_intensity;  // the frames of the previous launch and of the one before it
+    DevBuf<uint8_t> prev_rgb, prev2_rgb;
+    hipEvent_t out_done = nullptr, prev_out_done = nullptr, prev2_out_done = nullptr;  // traversal kernel of the last / previous / one before
+    uint64_t launch_seq = 0;                                    // launches of render_impl so far
+    uint64_t out_seq = 0, prev_out_seq = 0, prev2_out_seq = 0;  // the launch each of the three events was recorded behind (0: never)
     size_t n_nodes = 0, n_tlas = 0;
     double max_abs_coord = 0.0;  // largest |coordinate| of the uploaded scene (NaN/inf -> inf)
     int32_t stack_need = 1;
@@ -308,7 +311,7 @@ struct rt_ctx {
         int rows = 0, W = 0, spp = 0;
         int frames = 1;    // consecutive launches of that shape the slot holds the pairs of (small frames: several)
         hipEvent_t done = nullptr, t0 = nullptr, t1 = nullptr;
-        hipEvent_t read_done = nullptr;  // the traversal kernel that last read buf (refills wait for it)
+        uint64_t read_seq = 0;  // the launch whose traversal kernel read buf last (refills wait for it)
         bool read_pending = false;
         double host_ms = 0.0;
         // what d_states holds (survives `valid = false`): n states, `stride` words apart, from states_pos
@@ -342,6 +345,7 @@ struct rt_ctx {
     unsigned long long* stats_counters = nullptr;  // where the last launch's visit counters are (or null)
     unsigned char* static_scratch = nullptr;       // this GPU's copy of the file-scope `scratch` (rt_render_static)
     hipEvent_t static_done = nullptr;              // recorded behind every rt_render_static launch (created in rt_create)
+    bool skip_timing_events = false;               // this launch: no ev[0] / ev[1] around the traversal kernel (render_impl)
     DevBuf<uint32_t> gstack;
     int32_t out_rows = 0, out_w = 0, out_spp = 0;
     uint32_t out_flags = 0;
@@ -547,6 +551,21 @@ int sync_state(rt_ctx* c) {
     return RT_OK;
 }
 
+// The event behind which launch `seq` of this context is known to have finished: the oldest of the three rotating
+// out_done events that was recorded behind that launch or a later one (same stream: a later launch's end implies it).
+hipEvent_t done_event_for(rt_ctx* c, uint64_t seq) {
+    if (c->prev2_out_seq >= seq) return c->prev2_out_done;
+    if (c->prev_out_seq >= seq) return c->prev_out_done;
+    return c->out_done;
+}
+
+// The current scene set is about to be swapped out: its event (which travels with the buffers) is recorded now, behind
+// everything launched on it so far, instead of behind every launch.
+int retire_front(rt_ctx* c) {
+    if (c->front_used) HIP_TRY(hipEventRecord(c->front_last_use, c->stream));
+    return RT_OK;
+}
+
 // Generate the jitter of `frames` consecutive launches (rows x W x spp samples each, the first one starting `ahead`
 // words after the context's current position) into slot `k`, entirely on rng_stream.
 int fill_slot(rt_ctx* c, int k, uint64_t ahead, int rows, int W, int spp, int frames = 1, int hidden_n = 0) {
@@ -561,7 +580,7 @@ int fill_slot(rt_ctx* c, int k, uint64_t ahead, int rows, int W, int spp, int fr
     const double t0 = now_ms();
     std::future<void> end_poly;  // (joined by its destructor on every early return)
     // a traversal kernel launched earlier may still be reading this slot's pairs
-    if (sl.read_pending) HIP_TRY(hipStreamWaitEvent(c->rng_stream, sl.read_done, 0));
+    if (sl.read_pending) HIP_TRY(hipStreamWaitEvent(c->rng_stream, done_event_for(c, sl.read_seq), 0));
     HIP_TRY(hipEventRecord(sl.t0, c->rng_stream));
     // Steady state of a frame loop: the other slot holds the stream states of a launch of the same
     // shape D words earlier -> every state advances by D in ONE launch (instead of one jump to the
@@ -692,6 +711,7 @@ int stage_scene(rt_ctx* c, const rt::Scene& s) {
 // previous scene's buffers, guarded by the event of the last render that used them.
 void activate_staged(rt_ctx* c, int idx) {
     rt_ctx::StagedSet* st = c->staged[(size_t)idx].get();
+    (void)retire_front(c);
     swap_sets(c, st->b);
     std::swap(c->front_last_use, st->last_use);
     std::swap(c->front_used, st->used);
@@ -1026,7 +1046,8 @@ rt_ctx* rt_create(int device) {
         hipEventCreateWithFlags(&c->front_last_use, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->back_last_use, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->out_done, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->prev_out_done, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->prev_out_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->prev2_out_done, hipEventDisableTiming) != hipSuccess) {
         g_err = "rt_create: copy stream / events";
         return nullptr;
     }
@@ -1043,8 +1064,7 @@ rt_ctx* rt_create(int device) {
         return nullptr;
     }
     for (auto& cs : c->cam)
-        if (hipEventCreateWithFlags(&cs.ready, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&cs.read_done, hipEventDisableTiming) != hipSuccess) {
+        if (hipEventCreateWithFlags(&cs.ready, hipEventDisableTiming) != hipSuccess) {
             g_err = "rt_create: hipEventCreate failed";
             return nullptr;
         }
@@ -1055,8 +1075,7 @@ rt_ctx* rt_create(int device) {
         }
     for (auto& sl : c->slot)
         if (hipEventCreate(&sl.done) != hipSuccess || hipEventCreate(&sl.t0) != hipSuccess ||
-            hipEventCreate(&sl.t1) != hipSuccess ||
-            hipEventCreateWithFlags(&sl.read_done, hipEventDisableTiming) != hipSuccess) {
+            hipEventCreate(&sl.t1) != hipSuccess) {
             g_err = "rt_create: hipEventCreate failed";
             return nullptr;
         }
@@ -1107,7 +1126,6 @@ void rt_destroy(rt_ctx* c) {
         cs.tris.release();
         cs.cuts.release();
         if (cs.ready) (void)hipEventDestroy(cs.ready);
-        if (cs.read_done) (void)hipEventDestroy(cs.read_done);
     }
     c->nodes32.release();
     c->tlas32.release();
@@ -1127,7 +1145,6 @@ void rt_destroy(rt_ctx* c) {
         if (sl.done) (void)hipEventDestroy(sl.done);
         if (sl.t0) (void)hipEventDestroy(sl.t0);
         if (sl.t1) (void)hipEventDestroy(sl.t1);
-        if (sl.read_done) (void)hipEventDestroy(sl.read_done);
     }
     c->frame_intensity.release();
     c->frame_hit_t.release();
@@ -1166,8 +1183,11 @@ void rt_destroy(rt_ctx* c) {
     c->back.colors.release();
     if (c->out_done) (void)hipEventDestroy(c->out_done);
     if (c->prev_out_done) (void)hipEventDestroy(c->prev_out_done);
+    if (c->prev2_out_done) (void)hipEventDestroy(c->prev2_out_done);
     c->prev_intensity.release();
     c->prev_rgb.release();
+    c->prev2_intensity.release();
+    c->prev2_rgb.release();
     if (c->front_last_use) (void)hipEventDestroy(c->front_last_use);
     if (c->back_last_use) (void)hipEventDestroy(c->back_last_use);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
@@ -1196,6 +1216,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* scene) {
     if (c->back_used) HIP_TRY(hipEventSynchronize(c->back_last_use));
     int rc;
     if ((rc = copy_scene_to(c->back, s, c->copy_stream))) return rc;  // waits for the copies only
+    if ((rc = retire_front(c))) return rc;
     swap_sets(c, c->back);
     std::swap(c->front_last_use, c->back_last_use);
     std::swap(c->front_used, c->back_used);
@@ -1532,7 +1553,7 @@ int launch_packet_kernel(rt_ctx* c, const rt_render_params* p, int tile_log2, in
     a.spp_magic = 65536u / (uint32_t)std::max(spp, 1) + 1u;
     c->stats.finest_cut_level = a.cut_lo;  // (test seam: -1 = this launch walks from the root)
     if (cuts_made) *cuts_made = a.cut_lo >= 0;
-    HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+    if (!c->skip_timing_events) HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     if (count && a.pair64)
         hipLaunchKernelGGL((rtk::render_packet_kernel<true, true>), dim3((unsigned)n_tiles), dim3(rtk::NT), 0, c->stream, a);
     else if (count)
@@ -1542,7 +1563,7 @@ int launch_packet_kernel(rt_ctx* c, const rt_render_params* p, int tile_log2, in
     else
         hipLaunchKernelGGL((rtk::render_packet_kernel<false, false>), dim3((unsigned)n_tiles), dim3(rtk::NT), 0, c->stream, a);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    if (!c->skip_timing_events) HIP_TRY(hipEventRecord(c->ev[1], c->stream));
     return RT_OK;
 }
 
@@ -1648,6 +1669,8 @@ int render_impl(rt_ctx* c, const rt_render_params* p, bool pipelined) {
     rt_ctx::CamSet* cs = nullptr;
     CutPlan cp;
     // (small frames of small scenes: the two cross-stream dependencies cost more than the ~10 us of prep they hide)
+    // pipelined launches (the frame driver's, which never asks for a launch's statistics): no timing events around the kernel
+    c->skip_timing_events = pipelined;
     // (a frame that gets cuts always overlaps: the cut kernels are chains of dependent steps, ~0.3 ms of latency)
     const bool overlap = opt("RT_NO_PREP_OVERLAP") == nullptr &&  // (comparison knob, read per launch)
                          (n_smp >= (size_t(1) << 24) || c->n_tris >= (1 << 18) || cut_mode(W, rows, spp, tile_log2, c->n_tris) != 0);
@@ -1667,7 +1690,7 @@ int render_impl(rt_ctx* c, const rt_render_params* p, bool pipelined) {
         pb.counters = count ? c->counters.p : nullptr;
         const hipStream_t st = overlap ? c->prep_stream : c->stream;
         // the set was last read by the launch before the previous one (or by an fp32 launch)
-        if (overlap && cs->read_pending) HIP_TRY(hipStreamWaitEvent(st, cs->read_done, 0));
+        if (overlap && cs->read_pending) HIP_TRY(hipStreamWaitEvent(st, done_event_for(c, cs->read_seq), 0));
         if ((rc = launch_packet_prep(c, st, p, tile_log2, pb, pp))) return rc;
         if (overlap) HIP_TRY(hipEventRecord(cs->ready, st));
     }
@@ -1687,9 +1710,15 @@ int render_impl(rt_ctx* c, const rt_render_params* p, bool pipelined) {
 
     // the previous launch's frame moves to prev_* (its kernel may still be writing it: only the
     // pointers move); this launch writes the other pair
+    // (three pairs in rotation: the frame driver reads a frame back while the TWO launches after it are queued)
+    std::swap(c->prev_intensity, c->prev2_intensity);
+    std::swap(c->prev_rgb, c->prev2_rgb);
+    std::swap(c->prev_out_done, c->prev2_out_done);
+    std::swap(c->prev_out_seq, c->prev2_out_seq);
     std::swap(c->intensity, c->prev_intensity);
     std::swap(c->rgb, c->prev_rgb);
     std::swap(c->out_done, c->prev_out_done);
+    std::swap(c->out_seq, c->prev_out_seq);
     c->fp_idx ^= 1;
     DevBuf<rtk::FrameParams>& frame_params = c->frame_params_buf[c->fp_idx];
     rtk::FrameParams& h_frame_params = c->h_frame_params_buf[c->fp_idx];
@@ -1901,16 +1930,23 @@ int render_impl(rt_ctx* c, const rt_render_params* p, bool pipelined) {
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->ev[1], c->stream));
     }
-    if (cs) {  // the camera set's next prep (two launches on, on prep_stream) waits for this kernel
-        HIP_TRY(hipEventRecord(cs->read_done, c->stream));
+    // "This launch's kernel has finished" is what four parties wait for: the camera set's next prep, whoever reuses the
+    // scene set, the read-back of this frame, the refill of the jitter slot.  Every event record is a packet the
+    // traversal stream works off before it starts the next launch's kernel (~5 us each: most of the gap between the
+    // kernels of a loop of small frames), so ONE event is recorded per launch -- out_done, which rotates with the
+    // output buffers -- and the camera set and the jitter slot remember the launch number that read them last
+    // (done_event_for finds the rotating event that covers it); the scene set's event is recorded when the set is
+    // retired (retire_front).
+    HIP_TRY(hipEventRecord(c->out_done, c->stream));
+    c->out_seq = ++c->launch_seq;
+    if (cs) {
+        cs->read_seq = c->out_seq;
         cs->read_pending = true;
     }
-    HIP_TRY(hipEventRecord(c->front_last_use, c->stream));  // rt_upload_scene waits for it before reusing the set
     c->front_used = true;
-    HIP_TRY(hipEventRecord(c->out_done, c->stream));
-    HIP_TRY(hipEventRecord(c->slot[use].read_done, c->stream));
+    c->slot[use].read_seq = c->out_seq;
     c->slot[use].read_pending = true;
-    c->timing_pending = true;
+    c->timing_pending = !c->skip_timing_events;
     c->out_rows = rows;
     c->out_w = W;
     c->out_spp = spp;
@@ -1945,7 +1981,7 @@ int render_impl(rt_ctx* c, const rt_render_params* p, bool pipelined) {
             }
             const int other = 1 - use;
             // slot `other` was last read by an earlier call's kernel: fill_slot makes rng_stream wait
-            // for it (read_done); the slot's own jitter kernel is ordered on rng_stream.
+            // for it (read_seq); the slot's own jitter kernel is ordered on rng_stream.
             const int hidden_n = (c->adapt_n > 0 && c->adapt_rows == rows && c->adapt_w == W && c->adapt_spp == spp) ? c->adapt_n : 0;
             if (!covered && (rc = fill_slot(c, other, target - c->pos, rows, W, spp, group, hidden_n))) return rc;
         } catch (const std::exception&) {
@@ -2048,9 +2084,9 @@ int render_frame(rt_ctx* c, const rt_render_params* p, bool pipelined) {
 
 // rt_render_scene: the frame of the launch BEFORE the last one (pipelined launches), read back on the
 // copy stream while the last launch is still running
-int download_prev_rgb(rt_ctx* c, uint8_t* rgb, size_t n_bytes) {
-    HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->prev_out_done, 0));
-    HIP_TRY(hipMemcpyAsync(rgb, c->prev_rgb.p, n_bytes, hipMemcpyDeviceToHost, c->copy_stream));
+int download_prev_rgb(rt_ctx* c, uint8_t* rgb, size_t n_bytes, int age) {  // age 1: the previous launch's, 2: the one before
+    HIP_TRY(hipStreamWaitEvent(c->copy_stream, age == 2 ? c->prev2_out_done : c->prev_out_done, 0));
+    HIP_TRY(hipMemcpyAsync(rgb, age == 2 ? c->prev2_rgb.p : c->prev_rgb.p, n_bytes, hipMemcpyDeviceToHost, c->copy_stream));
     HIP_TRY(hipStreamSynchronize(c->copy_stream));
     return RT_OK;
 }
@@ -2535,9 +2571,20 @@ int rt_render_scene(int image_height, int image_width, int number_of_samples, co
         probe.sampler = RT_SAMPLER_MT19937;
         if (band_rows_for(&probe) != 0) pipeline = false;
     }
-    bool have_prev = false;
-    int prev_t = 0, prev_cam = 0;
+    std::deque<std::pair<int, int>> in_flight;  // (timestep, camera) of the frames queued and not yet read back, oldest first
+    const int ahead = opt("RT_FRAMES_AHEAD") ? std::max(1, std::min(2, std::atoi(opt("RT_FRAMES_AHEAD")))) : 2;  // (comparison knob)
     int64_t pending_sah_lines = 0;
+    auto frame_path = [&](int tt, int cc) {
+        // cpp/rtmain.cpp:58-60: rtimage_<timestep>_cam<camera>.ppm, zero-based
+        return std::string(output_directory) + "/rtimage_" + std::to_string(tt) + "_cam" + std::to_string(cc) + ".ppm";
+    };
+    auto write_async = [&](const std::string& path, uint8_t* src) {
+        // like the reference, an unopenable file is reported and the job goes on
+        writer = writer_thread().submit([path, image_width, image_height, src]() {
+            (void)rt_write_ppm(path.c_str(), image_width, image_height, src);
+        });
+        wbuf ^= 1;
+    };
     top_up();
     int built_t = -1;
     for (int64_t q = 0; q < n_mine; ++q) {
@@ -2600,32 +2647,22 @@ int rt_render_scene(int image_height, int image_width, int number_of_samples, co
         if ((rc = render_frame(c, &p, pipeline))) return bail(rc);
         t_render += now() - t1;
         if (trace) std::fprintf(stderr, "  f%lld t%d c%d: enqueue %.3f .. %.3f ms\n", (long long)q, t, cam, (t1 - t_job0) * 1e3, (now() - t_job0) * 1e3);
-        auto frame_path = [&](int tt, int cc) {
-            // cpp/rtmain.cpp:58-60: rtimage_<timestep>_cam<camera>.ppm, zero-based
-            return std::string(output_directory) + "/rtimage_" + std::to_string(tt) + "_cam" + std::to_string(cc) + ".ppm";
-        };
-        auto write_async = [&](const std::string& path, uint8_t* src) {
-            // like the reference, an unopenable file is reported and the job goes on
-            writer = writer_thread().submit([path, image_width, image_height, src]() {
-                (void)rt_write_ppm(path.c_str(), image_width, image_height, src);
-            });
-            wbuf ^= 1;
-        };
         if (pipeline) {
-            if (have_prev) {
+            // this frame is queued; the oldest of the frames in flight is read back once `ahead` younger ones are queued
+            // behind it (2: the GPU always has the next frame's kernels waiting when one ends)
+            in_flight.emplace_back(t, cam);
+            if ((int)in_flight.size() > ahead) {
                 t1 = now();
                 if (writer.valid()) writer.get();
                 uint8_t* dst = rgb2[wbuf].data();
-                if ((rc = download_prev_rgb(c, dst, rgb_bytes))) return bail(rc);
+                if ((rc = download_prev_rgb(c, dst, rgb_bytes, (int)in_flight.size() - 1))) return bail(rc);
                 t_down += now() - t1;
-                if (trace) std::fprintf(stderr, "      download of previous frame %.3f .. %.3f ms\n", (t1 - t_job0) * 1e3, (now() - t_job0) * 1e3);
+                if (trace) std::fprintf(stderr, "      download of an earlier frame %.3f .. %.3f ms\n", (t1 - t_job0) * 1e3, (now() - t_job0) * 1e3);
                 t1 = now();
-                write_async(frame_path(prev_t, prev_cam), dst);
+                write_async(frame_path(in_flight.front().first, in_flight.front().second), dst);
+                in_flight.pop_front();
                 t_write += now() - t1;
             }
-            have_prev = true;
-            prev_t = t;
-            prev_cam = cam;
         }
         // the tree of the next timestep becomes current (pointer swap; its helper thread has already
         // copied it to the GPU) while this timestep's last frame is still rendering
@@ -2644,17 +2681,17 @@ int rt_render_scene(int image_height, int image_width, int number_of_samples, co
             t_write += now() - t1;
         }
     }
-    if (pipeline && have_prev) {  // the last frame
+    while (pipeline && !in_flight.empty()) {  // the last frames, oldest first
         if (writer.valid()) writer.get();
         uint8_t* dst = rgb2[wbuf].data();
-        if ((rc = rt_download(c, nullptr, dst, nullptr, nullptr))) {
+        const int age = (int)in_flight.size() - 1;
+        rc = age == 0 ? rt_download(c, nullptr, dst, nullptr, nullptr) : download_prev_rgb(c, dst, rgb_bytes, age);
+        if (rc) {
             drain();
             return rc;
         }
-        (void)rt_write_ppm((std::string(output_directory) + "/rtimage_" + std::to_string(prev_t) + "_cam" +
-                            std::to_string(prev_cam) + ".ppm")
-                               .c_str(),
-                           image_width, image_height, dst);
+        write_async(frame_path(in_flight.front().first, in_flight.front().second), dst);
+        in_flight.pop_front();
     }
     if (writer.valid()) writer.get();
     if (timing)
