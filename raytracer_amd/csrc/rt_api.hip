@@ -2572,7 +2572,10 @@ int rt_render_scene(int image_height, int image_width, int number_of_samples, co
         if (band_rows_for(&probe) != 0) pipeline = false;
     }
     std::deque<std::pair<int, int>> in_flight;  // (timestep, camera) of the frames queued and not yet read back, oldest first
-    const int ahead = opt("RT_FRAMES_AHEAD") ? std::max(1, std::min(2, std::atoi(opt("RT_FRAMES_AHEAD")))) : 2;  // (comparison knob)
+    // (comparison knob.  2 -- read a frame back when TWO younger ones are queued -- buys nothing in one process, measured,
+    // and with two processes on one GPU, both with kernels queued at all times, the GPU did little but switch between
+    // them: 5 frames/s each instead of 245)
+    const int ahead = opt("RT_FRAMES_AHEAD") ? std::max(1, std::min(2, std::atoi(opt("RT_FRAMES_AHEAD")))) : 1;
     int64_t pending_sah_lines = 0;
     auto frame_path = [&](int tt, int cc) {
         // cpp/rtmain.cpp:58-60: rtimage_<timestep>_cam<camera>.ppm, zero-based
@@ -2649,7 +2652,7 @@ int rt_render_scene(int image_height, int image_width, int number_of_samples, co
         if (trace) std::fprintf(stderr, "  f%lld t%d c%d: enqueue %.3f .. %.3f ms\n", (long long)q, t, cam, (t1 - t_job0) * 1e3, (now() - t_job0) * 1e3);
         if (pipeline) {
             // this frame is queued; the oldest of the frames in flight is read back once `ahead` younger ones are queued
-            // behind it (2: the GPU always has the next frame's kernels waiting when one ends)
+            // behind it
             in_flight.emplace_back(t, cam);
             if ((int)in_flight.size() > ahead) {
                 t1 = now();
