@@ -2572,9 +2572,7 @@ int rt_render_scene(int image_height, int image_width, int number_of_samples, co
         if (band_rows_for(&probe) != 0) pipeline = false;
     }
     std::deque<std::pair<int, int>> in_flight;  // (timestep, camera) of the frames queued and not yet read back, oldest first
-    // (comparison knob.  2 -- read a frame back when TWO younger ones are queued -- buys nothing in one process, measured,
-    // and with two processes on one GPU, both with kernels queued at all times, the GPU did little but switch between
-    // them: 5 frames/s each instead of 245)
+    // (comparison knob.  2 -- read a frame back when TWO younger ones are queued -- buys nothing, measured)
     const int ahead = opt("RT_FRAMES_AHEAD") ? std::max(1, std::min(2, std::atoi(opt("RT_FRAMES_AHEAD")))) : 1;
     int64_t pending_sah_lines = 0;
     auto frame_path = [&](int tt, int cc) {
