@@ -122,17 +122,20 @@ struct Box {
     // time with SSE2 (x86-64 baseline): MINPD(p, m) is (p < m) ? p : m and MAXPD(p, m) is (p > m) ? p : m lane by
     // lane -- the second operand whenever the comparison is false, NaNs and equal zeros included -- i.e. exactly the
     // two expressions above with p the incoming value and m the running extreme.
+    // mn[2] and mx[0] are neighbours in memory: the middle pair takes its low half from the MINPD and its high half
+    // from the MAXPD of the same two operands (three 16-byte updates per box instead of two and two scalar ones).
     void add_point(const double* p) {
-        const __m128d p01 = _mm_loadu_pd(p);
+        const __m128d p01 = _mm_loadu_pd(p), p12 = _mm_loadu_pd(p + 1);
+        const __m128d p20 = _mm_shuffle_pd(p12, p01, 1);  // (p[2], p[0])
+        const __m128d m20 = _mm_loadu_pd(mn + 2);
         _mm_storeu_pd(mn, _mm_min_pd(p01, _mm_loadu_pd(mn)));
-        _mm_storeu_pd(mx, _mm_max_pd(p01, _mm_loadu_pd(mx)));
-        mn[2] = (p[2] < mn[2]) ? p[2] : mn[2];
-        mx[2] = (mx[2] < p[2]) ? p[2] : mx[2];
+        _mm_storeu_pd(mn + 2, _mm_move_sd(_mm_max_pd(p20, m20), _mm_min_pd(p20, m20)));
+        _mm_storeu_pd(mx + 1, _mm_max_pd(p12, _mm_loadu_pd(mx + 1)));
     }
     void add_box(const Box& o) {
+        const __m128d o20 = _mm_loadu_pd(o.mn + 2), m20 = _mm_loadu_pd(mn + 2);
         _mm_storeu_pd(mn, _mm_min_pd(_mm_loadu_pd(o.mn), _mm_loadu_pd(mn)));
-        mn[2] = (o.mn[2] < mn[2]) ? o.mn[2] : mn[2];
-        mx[0] = (mx[0] < o.mx[0]) ? o.mx[0] : mx[0];
+        _mm_storeu_pd(mn + 2, _mm_move_sd(_mm_max_pd(o20, m20), _mm_min_pd(o20, m20)));
         _mm_storeu_pd(mx + 1, _mm_max_pd(_mm_loadu_pd(o.mx + 1), _mm_loadu_pd(mx + 1)));
     }
     double extent(int axis) const {
@@ -145,6 +148,8 @@ struct Box {
         return 2 * (h * w + w * d + h * d);
     }
 };
+
+static_assert(sizeof(Box) == 6 * sizeof(double), "Box: mn[3] and mx[3] back to back");
 
 struct Centroid {
     double c[3];
@@ -477,6 +482,16 @@ bool choose_split(const Elements& el, const int32_t* idx, int64_t first, int64_t
     const bool with_cent = sides != nullptr && count < kParMin;
     if (with_cent) {
         for (int b = 0; b < kBins; ++b) bin_cent[b].reset();
+        if (const Rec* const rec = el.rec) {  // (the same loop on the records themselves: no per-element dispatch)
+            for (const Rec *r = rec + first, *const re = r + count; r != re; ++r) {
+                const double t = (r->c.c[axis] - cmin) * inv_ext;
+                int b = static_cast<int>(t * kBins);
+                b = b == kBins ? kBins - 1 : b;
+                bin_cnt[b]++;
+                bin_box[b].add_box(r->box);
+                bin_cent[b].add_point(r->c.c);
+            }
+        } else
         for (int64_t i = first; i < first + count; ++i) {
             const double* cc = elem_cent(el, idx, i);
             double t = (cc[axis] - cmin) * inv_ext;
@@ -570,10 +585,15 @@ bool choose_split(const Elements& el, const int32_t* idx, int64_t first, int64_t
         rb.reset();
         lc.reset();
         rc.reset();
-        for (int b = 0; b < kBins; ++b) {
+        for (int b = 0; b <= best_bin; ++b) {
             if (bin_cnt[b] == 0) continue;
-            (b <= best_bin ? lb : rb).add_box(bin_box[b]);
-            (b <= best_bin ? lc : rc).add_box(bin_cent[b]);
+            lb.add_box(bin_box[b]);
+            lc.add_box(bin_cent[b]);
+        }
+        for (int b = best_bin + 1; b < kBins; ++b) {
+            if (bin_cnt[b] == 0) continue;
+            rb.add_box(bin_box[b]);
+            rc.add_box(bin_cent[b]);
         }
         // both sides are non-empty here (the boundary was valid); the partition's test is `centroid < pos_out`
         if (lc.mx[axis] < pos_out && !(rc.mn[axis] < pos_out)) {
@@ -788,6 +808,7 @@ int64_t partition(const Elements& el, int32_t* idx, int64_t first, int64_t count
         if (nl == 0 || nl == count) return -1;
         return nl;
     }
+    Rec* const rec = el.rec;
     if (fold && sides && count < kParMin && !sides_ready) {
         Box lb, rb, lc, rc;
         lb.reset();
@@ -817,6 +838,16 @@ int64_t partition(const Elements& el, int32_t* idx, int64_t first, int64_t count
         sides->box_ok[1] = no_zero_component(rb);
         sides->cent_ok[0] = no_zero_component(lc);
         sides->cent_ok[1] = no_zero_component(rc);
+    } else if (rec) {  // (the loop below on the records themselves)
+        while (mid < end) {
+            if (rec[mid].c.c[axis] < pos) {
+                ++mid;
+            } else {
+                --end;
+                std::swap(idx[mid], idx[end]);
+                std::swap(rec[mid], rec[end]);
+            }
+        }
     } else {
         while (mid < end) {
             if (elem_cent(el, idx, mid)[axis] < pos) {
@@ -824,7 +855,6 @@ int64_t partition(const Elements& el, int32_t* idx, int64_t first, int64_t count
             } else {
                 --end;
                 std::swap(idx[mid], idx[end]);
-                if (el.rec) std::swap(el.rec[mid], el.rec[end]);
             }
         }
     }
@@ -1084,24 +1114,59 @@ void build_one_blas(HostBlas& b, int32_t mesh, const double* coords_t, int64_t E
     FlatVec<Rec> rec(static_cast<size_t>(E));  // (not zero-filled first) boxes + centroids, permuted together with the index array
     Box mesh_box;
     mesh_box.reset();
+    std::atomic<bool> non_finite{false};
     {
         const int64_t max_chunks = E < kParMin ? 1 : (E + kParChunk - 1) / kParChunk;
         std::vector<Box> part(static_cast<size_t>(max_chunks));
         int64_t nc = 0;
         for_chunks(0, E, nc, [&](int64_t c, int64_t lo, int64_t hi) {
-            Box mb;
-            mb.reset();
+            // rtbvh.cpp:48-78: centroid (v0 + v1 + v2) / 3.0 per component (:20-27), box = the three vertices added to an
+            // empty box in order, mesh box += box: Box::add_point / add_box spelt out on registers (the same MINPD /
+            // MAXPD with the incoming value first, x and y as a pair, z alone; the divisions stay divisions) -- through
+            // the records in memory the loop was three times as long
+            const __m128d inf2 = _mm_set1_pd(kInf), ninf2 = _mm_set1_pd(-kInf), three2 = _mm_set1_pd(3.0);
+            __m128d mb_mn01 = inf2, mb_mx01 = ninf2, mb_mn2 = inf2, mb_mx2 = ninf2, bad = _mm_setzero_pd();
             for (int64_t e = lo; e < hi; ++e) {
                 const double* tc = coords_t + e * 9;
-                for (int i = 0; i < 3; ++i) rec[e].c.c[i] = (tc[i] + tc[i + 3] + tc[i + 6]) / 3.0;
-                rec[e].box.reset();
-                for (int v = 0; v < 3; ++v) rec[e].box.add_point(tc + 3 * v);
-                mb.add_box(rec[e].box);
+                const __m128d a01 = _mm_loadu_pd(tc), b01 = _mm_loadu_pd(tc + 3), c01 = _mm_loadu_pd(tc + 6);
+                const __m128d a2 = _mm_load_sd(tc + 2), b2 = _mm_load_sd(tc + 5), c2 = _mm_load_sd(tc + 8);
+                Rec& r = rec[e];
+                const __m128d cen01 = _mm_div_pd(_mm_add_pd(_mm_add_pd(a01, b01), c01), three2);
+                const __m128d cen2 = _mm_div_sd(_mm_add_sd(_mm_add_sd(a2, b2), c2), three2);
+                _mm_storeu_pd(r.c.c, cen01);
+                _mm_store_sd(r.c.c + 2, cen2);
+                // (x - x is a NaN exactly when x is a NaN or an infinity)
+                const __m128d z01 = _mm_sub_pd(cen01, cen01), z2 = _mm_sub_sd(cen2, cen2);
+                bad = _mm_or_pd(bad, _mm_or_pd(_mm_cmpunord_pd(z01, z01), _mm_cmpunord_sd(z2, z2)));
+                const __m128d mn01 = _mm_min_pd(c01, _mm_min_pd(b01, _mm_min_pd(a01, inf2)));
+                const __m128d mx01 = _mm_max_pd(c01, _mm_max_pd(b01, _mm_max_pd(a01, ninf2)));
+                const __m128d mn2 = _mm_min_sd(c2, _mm_min_sd(b2, _mm_min_sd(a2, inf2)));
+                const __m128d mx2 = _mm_max_sd(c2, _mm_max_sd(b2, _mm_max_sd(a2, ninf2)));
+                _mm_storeu_pd(r.box.mn, mn01);
+                _mm_store_sd(r.box.mn + 2, mn2);
+                _mm_storeu_pd(r.box.mx, mx01);
+                _mm_store_sd(r.box.mx + 2, mx2);
+                mb_mn01 = _mm_min_pd(mn01, mb_mn01);
+                mb_mx01 = _mm_max_pd(mx01, mb_mx01);
+                mb_mn2 = _mm_min_sd(mn2, mb_mn2);
+                mb_mx2 = _mm_max_sd(mx2, mb_mx2);
             }
+            Box mb;
+            _mm_storeu_pd(mb.mn, mb_mn01);
+            _mm_store_sd(mb.mn + 2, mb_mn2);
+            _mm_storeu_pd(mb.mx, mb_mx01);
+            _mm_store_sd(mb.mx + 2, mb_mx2);
             part[c] = mb;
+            if (_mm_movemask_pd(bad)) non_finite.store(true, std::memory_order_relaxed);
         });
         for (int64_t c = 0; c < nc; ++c) mesh_box.add_box(part[c]);
     }
+    // A centroid that is a NaN or an infinity (such vertex coordinates, or a sum that overflows) turns the reference's
+    // bin index static_cast<int>(t * NUM_BINS) (rtbvh.cpp:184) into undefined behaviour -- an out-of-range write on
+    // x86-64 -- as soon as the mesh is split at all (more than 4 triangles): refused here instead.
+    if (non_finite.load(std::memory_order_relaxed) && E > 4)
+        throw std::runtime_error("mesh " + std::to_string(mesh) +
+                                 ": a triangle's centroid is not finite (NaN, infinite or overflowing vertex coordinates)");
     for (int i = 0; i < 3; ++i) mesh_cent.c[i] = (mesh_box.mn[i] + mesh_box.mx[i]) / 2.0;
     std::memcpy(b.mn, mesh_box.mn, sizeof(b.mn));
     std::memcpy(b.mx, mesh_box.mx, sizeof(b.mx));
@@ -1247,6 +1312,11 @@ Scene* build_scene(int n_meshes, const double* const* coords, const double* cons
     }
     std::vector<int32_t> blas_idx(static_cast<size_t>(n_meshes));
     for (int m = 0; m < n_meshes; ++m) blas_idx[m] = m;
+    if (n_meshes > 2)  // (the TLAS is split from three meshes on: the same bin index, rtbvh.cpp:184)
+        for (int m = 0; m < n_meshes; ++m)
+            for (int i = 0; i < 3; ++i)
+                if (!std::isfinite(mesh_cent[m].c[i]))
+                    throw std::runtime_error("mesh " + std::to_string(m) + ": the centre of its bounding box is not finite");
     Elements mel{mesh_cent.data(), mesh_boxes.data()};
     build_tree(sc->tlas, mel, blas_idx.data(), n_meshes, 2, sc->midpoint_fallbacks);
 
@@ -1302,7 +1372,8 @@ Scene* build_scene(int n_meshes, const double* const* coords, const double* cons
             std::vector<double> part(static_cast<size_t>(E < kParMin ? 1 : (E + kParChunk - 1) / kParChunk), 0.0);
             int64_t nc = 0;
             for_chunks(0, E, nc, [&](int64_t c, int64_t lo, int64_t hi) {
-                double m = 0.0;
+                const __m128d absmask = _mm_castsi128_pd(_mm_set1_epi64x(0x7fffffffffffffffll));
+                __m128d vmax = _mm_setzero_pd(), vnan = _mm_setzero_pd();
                 for (int64_t p = lo; p < hi; ++p) {
                     const int64_t e = b.sorted_to_elem[p];
                     double* const dst = &sc->tris[(tb + p) * 9];
@@ -1310,12 +1381,19 @@ Scene* build_scene(int n_meshes, const double* const* coords, const double* cons
                     std::memcpy(&sc->colors[(tb + p) * 3], kt + e * 3, 3 * sizeof(double));
                     sc->prim_mesh[tb + p] = b.mesh;
                     sc->prim_elem[tb + p] = static_cast<int32_t>(e);
-                    for (int j = 0; j < 9; ++j) {
-                        const double a = std::fabs(dst[j]);
-                        if (!(a <= m)) m = (a == a) ? a : kInf;
-                    }
+                    // |x| pairwise; MAXPD keeps the running maximum when the incoming value is a NaN, so NaNs are
+                    // noted apart (x != x) and turn the result into infinity at the end
+                    const __m128d x01 = _mm_loadu_pd(dst), x23 = _mm_loadu_pd(dst + 2), x45 = _mm_loadu_pd(dst + 4),
+                                  x67 = _mm_loadu_pd(dst + 6), x88 = _mm_load1_pd(dst + 8);
+                    vmax = _mm_max_pd(_mm_max_pd(_mm_and_pd(x01, absmask), _mm_and_pd(x23, absmask)),
+                                      _mm_max_pd(_mm_max_pd(_mm_and_pd(x45, absmask), _mm_and_pd(x67, absmask)),
+                                                 _mm_max_pd(_mm_and_pd(x88, absmask), vmax)));
+                    vnan = _mm_or_pd(vnan, _mm_or_pd(_mm_or_pd(_mm_cmpunord_pd(x01, x23), _mm_cmpunord_pd(x45, x67)),
+                                                     _mm_cmpunord_pd(x88, x88)));
                 }
-                part[static_cast<size_t>(c)] = m;
+                double m2[2];
+                _mm_storeu_pd(m2, vmax);
+                part[static_cast<size_t>(c)] = _mm_movemask_pd(vnan) ? kInf : std::max(m2[0], m2[1]);
             });
             double m = 0.0;
             for (int64_t c = 0; c < nc; ++c)

@@ -4,6 +4,7 @@
 // hits can be checked against it.  The layout is ours: one flat 64-byte node array, one flat
 // triangle array in leaf order, one colour array, a slot table.  See DESIGN.md "Data layout".
 #pragma once
+#include <cstddef>
 #include <cstdint>
 #include <new>
 #include <utility>

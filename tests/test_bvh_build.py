@@ -212,3 +212,42 @@ def test_parallel_partition_is_the_serial_two_pointer_permutation():
     assert L.lib.rt_partition_selftest(1_000_000, 12345, 40) == 0
     assert L.lib.rt_partition_selftest(20_000, 777, 600) == 0
     assert L.lib.rt_partition_selftest(200, 99, 200_000) == 0
+
+
+def test_signed_zero_coordinates_build_the_same_tree():
+    """std::min / std::max keep the FIRST of two equal zeros (rtbvh.h AABB::expand_*): the builder's SSE2 box updates
+    (record init on registers, three 16-byte updates per box, bins, sides from bin unions) must reproduce that, bit for
+    bit, on coordinates full of +0.0 and -0.0."""
+    rng = np.random.default_rng(77)
+    for trial in range(6):
+        c, k = meshgen.random_soup(int(rng.integers(40, 900)), seed=500 + trial, extent=2.0, size=0.7)
+        flat = c.reshape(-1)
+        n = flat.size
+        flat[rng.integers(0, n, n // 6)] = 0.0
+        flat[rng.integers(0, n, n // 6)] = -0.0
+        assert_same_tree([c], [k])
+        c2, k2 = meshgen.random_soup(30, seed=900 + trial, extent=1.0)
+        assert_same_tree([c, c2 + 3.0], [k, k2])
+
+
+def test_non_finite_centroids_are_refused_where_the_reference_indexes_its_bins_with_them():
+    """A NaN or infinite centroid makes `static_cast<int>(t * NUM_BINS)` (rtbvh.cpp:184) undefined behaviour as soon as
+    the mesh is split (more than 4 triangles; the TLAS: more than 2 meshes): an error, not a crash.  Meshes the reference
+    never splits are built as they are, NaNs and all (std::min / std::max skip an incoming NaN)."""
+    from raytracer_amd._lib import RtError
+    for bad in (np.nan, np.inf, -np.inf, 1.7e308):
+        c, k = meshgen.random_soup(200, seed=5, extent=2.0, size=0.7)
+        c.reshape(-1)[37] = bad
+        if bad == 1.7e308:
+            c.reshape(-1)[40] = bad  # the same component of the next vertex: the centroid's sum overflows
+        with pytest.raises(RtError, match="not finite"):
+            ra.HostScene([c], [k], 0)
+        c4, k4 = meshgen.random_soup(4, seed=6)
+        c4.reshape(-1)[5] = bad
+        if np.isnan(bad):
+            assert_same_tree([c4], [k4])
+    many = [meshgen.random_soup(3, seed=10 + m) for m in range(3)]
+    many[1][0].reshape(-1)[2] = np.inf
+    with pytest.raises(RtError, match="not finite"):
+        ra.HostScene([m[0] for m in many], [m[1] for m in many], 0)
+    assert_same_tree([m[0] for m in many[:2]], [m[1] for m in many[:2]])  # two meshes: one TLAS leaf, no split
