@@ -17,6 +17,15 @@ int main(int argc, char** argv) {
             int t[2][3] = {{0, 1, 2}, {1, 3, 2}};
             for (auto& tt : t) { for (int q : tt) for (int d = 0; d < 3; ++d) c.push_back(v[q][d]); for (int d = 0; d < 3; ++d) k.push_back(0.5); }
         }
+    if (argc > 2) {  // "soup": the same number of small triangles at random places, in random order (no spatial runs)
+        unsigned long long x = 88172645463325252ull;
+        auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return (x >> 11) * (1.0 / 9007199254740992.0); };
+        for (size_t t = 0; t < c.size() / 9; ++t) {
+            const double o[3] = {rnd() * 5.0, rnd() * 5.0, -6.0 + rnd()};
+            for (int v = 0; v < 3; ++v)
+                for (int d = 0; d < 3; ++d) c[t * 9 + v * 3 + d] = o[d] + 0.05 * rnd();
+        }
+    }
     int64_t E = c.size() / 9;
     const double* cp = c.data(); const double* kp = k.data();
     double best = 1e9;
