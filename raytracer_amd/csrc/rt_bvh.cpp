@@ -180,6 +180,7 @@ inline const double* elem_cent(const Elements& el, const int32_t* idx, int64_t i
 // mesh's elements are stored in some spatial order, and the partition keeps runs of it), and updating a bin in memory
 // for each of them is a chain of store-to-load forwards -- ten cycles an element.  The same minimum / maximum
 // operations in the same order, the bin written back when the run ends: the same bits.
+template <bool CENT>
 void bin_records_runs(const Rec* r, const Rec* const re, int axis, double cmin, double inv_ext, Box* box, Box* cent,
                       uint32_t* cnt) {
     int cur = -1;
@@ -194,9 +195,11 @@ void bin_records_runs(const Rec* r, const Rec* const re, int axis, double cmin, 
                 _mm_storeu_pd(box[cur].mn, b01);
                 _mm_storeu_pd(box[cur].mn + 2, b20);
                 _mm_storeu_pd(box[cur].mx + 1, b12);
-                _mm_storeu_pd(cent[cur].mn, c01);
-                _mm_storeu_pd(cent[cur].mn + 2, c20);
-                _mm_storeu_pd(cent[cur].mx + 1, c12);
+                if (CENT) {
+                    _mm_storeu_pd(cent[cur].mn, c01);
+                    _mm_storeu_pd(cent[cur].mn + 2, c20);
+                    _mm_storeu_pd(cent[cur].mx + 1, c12);
+                }
                 cnt[cur] += n;
             }
             cur = b;
@@ -204,28 +207,34 @@ void bin_records_runs(const Rec* r, const Rec* const re, int axis, double cmin, 
             b01 = _mm_loadu_pd(box[b].mn);
             b20 = _mm_loadu_pd(box[b].mn + 2);
             b12 = _mm_loadu_pd(box[b].mx + 1);
-            c01 = _mm_loadu_pd(cent[b].mn);
-            c20 = _mm_loadu_pd(cent[b].mn + 2);
-            c12 = _mm_loadu_pd(cent[b].mx + 1);
+            if (CENT) {
+                c01 = _mm_loadu_pd(cent[b].mn);
+                c20 = _mm_loadu_pd(cent[b].mn + 2);
+                c12 = _mm_loadu_pd(cent[b].mx + 1);
+            }
         }
         ++n;
         const __m128d e01 = _mm_loadu_pd(r->box.mn), e20 = _mm_loadu_pd(r->box.mn + 2), e12 = _mm_loadu_pd(r->box.mx + 1);
         b01 = _mm_min_pd(e01, b01);
         b20 = _mm_move_sd(_mm_max_pd(e20, b20), _mm_min_pd(e20, b20));
         b12 = _mm_max_pd(e12, b12);
-        const __m128d p01 = _mm_loadu_pd(r->c.c), p12 = _mm_loadu_pd(r->c.c + 1);
-        const __m128d p20 = _mm_shuffle_pd(p12, p01, 1);  // (c[2], c[0])
-        c01 = _mm_min_pd(p01, c01);
-        c20 = _mm_move_sd(_mm_max_pd(p20, c20), _mm_min_pd(p20, c20));
-        c12 = _mm_max_pd(p12, c12);
+        if (CENT) {
+            const __m128d p01 = _mm_loadu_pd(r->c.c), p12 = _mm_loadu_pd(r->c.c + 1);
+            const __m128d p20 = _mm_shuffle_pd(p12, p01, 1);  // (c[2], c[0])
+            c01 = _mm_min_pd(p01, c01);
+            c20 = _mm_move_sd(_mm_max_pd(p20, c20), _mm_min_pd(p20, c20));
+            c12 = _mm_max_pd(p12, c12);
+        }
     }
     if (cur >= 0) {
         _mm_storeu_pd(box[cur].mn, b01);
         _mm_storeu_pd(box[cur].mn + 2, b20);
         _mm_storeu_pd(box[cur].mx + 1, b12);
-        _mm_storeu_pd(cent[cur].mn, c01);
-        _mm_storeu_pd(cent[cur].mn + 2, c20);
-        _mm_storeu_pd(cent[cur].mx + 1, c12);
+        if (CENT) {
+            _mm_storeu_pd(cent[cur].mn, c01);
+            _mm_storeu_pd(cent[cur].mn + 2, c20);
+            _mm_storeu_pd(cent[cur].mx + 1, c12);
+        }
         cnt[cur] += n;
     }
 }
@@ -553,7 +562,7 @@ bool choose_split(const Elements& el, const int32_t* idx, int64_t first, int64_t
     if (with_cent) {
         for (int b = 0; b < kBins; ++b) bin_cent[b].reset();
         if (el.rec && count >= g_runs_min && bins_come_in_runs(el.rec + first, axis, cmin, inv_ext)) {
-            bin_records_runs(el.rec + first, el.rec + first + count, axis, cmin, inv_ext, bin_box, bin_cent, bin_cnt);
+            bin_records_runs<true>(el.rec + first, el.rec + first + count, axis, cmin, inv_ext, bin_box, bin_cent, bin_cnt);
         } else if (const Rec* const rec = el.rec) {  // (the same loop on the records themselves: no per-element dispatch)
             for (const Rec *r = rec + first, *const re = r + count; r != re; ++r) {
                 const double t = (r->c.c[axis] - cmin) * inv_ext;
@@ -594,6 +603,10 @@ bool choose_split(const Elements& el, const int32_t* idx, int64_t first, int64_t
             for (int b = 0; b < kBins; ++b) {
                 p.box[b].reset();
                 p.cnt[b] = 0;
+            }
+            if (el.rec && hi - lo >= g_runs_min && bins_come_in_runs(el.rec + lo, axis, cmin, inv_ext)) {
+                bin_records_runs<false>(el.rec + lo, el.rec + hi, axis, cmin, inv_ext, p.box, nullptr, p.cnt);
+                return;
             }
             for (int64_t i = lo; i < hi; ++i) {
                 double t = (elem_cent(el, idx, i)[axis] - cmin) * inv_ext;
