@@ -59,7 +59,7 @@ int fail(int code, const std::string& msg) {
 // -- by the first rt_create, or by the first host-only call that needs one -- and again only on rt_reload_options():
 // no render, upload or driver call reaches getenv.  opt("RT_X") returns the value taken then, or null when unset,
 // so each site keeps the meaning it had when it asked the environment itself.
-const char* const kOptionNames[] = {"RT_ADAPT_MIN_WORDS", "RT_ADAPT_RATIO", "RT_BUILD_AHEAD", "RT_BUILD_TIMING", "RT_COUNT_WITH_CUTS", "RT_CUT1_CAP", "RT_CUT1_MAX_TRIS_PER_BLOCK", "RT_CUT1_MIN_RAYS", "RT_CUT1_SERIAL", "RT_CUT_LO", "RT_CUT_MIN_RAYS", "RT_CUT_STEP", "RT_CUT_TOP", "RT_CUT_TOPCAP", "RT_DRIVER_TIMING", "RT_FORCE_PERLANE", "RT_FRAMES_AHEAD", "RT_INTERLEAVE", "RT_JITTER_SLOT_BYTES", "RT_JITTER_STREAMS", "RT_NO_ADAPT_STREAMS", "RT_NO_CUT", "RT_NO_FRAME_GROUPS", "RT_NO_INTERLEAVE", "RT_NO_LOOKAHEAD", "RT_NO_PAIR64", "RT_NO_PIPELINE", "RT_NO_PREP_OVERLAP", "RT_NO_SERIAL_TREES", "RT_NO_SMALL_TILES", "RT_NO_STATE_REUSE", "RT_NO_TRIM", "RT_PAD64_FROM", "RT_RNG_PRIO", "RT_STAGE_STREAMS", "RT_TILE_LOG2"};
+const char* const kOptionNames[] = {"RT_ADAPT_MIN_WORDS", "RT_ADAPT_RATIO", "RT_BUILD_AHEAD", "RT_BUILD_TIMING", "RT_COUNT_WITH_CUTS", "RT_CUT1_CAP", "RT_CUT1_MAX_TRIS_PER_BLOCK", "RT_CUT1_MIN_RAYS", "RT_CUT1_SERIAL", "RT_CUT_LO", "RT_CUT_MIN_RAYS", "RT_CUT_STEP", "RT_CUT_TOP", "RT_CUT_TOPCAP", "RT_DRIVER_TIMING", "RT_FORCE_PERLANE", "RT_FRAMES_AHEAD", "RT_INTERLEAVE", "RT_JITTER_SLOT_BYTES", "RT_JITTER_STREAMS", "RT_NO_ADAPT_STREAMS", "RT_NO_CUT", "RT_NO_FRAME_GROUPS", "RT_NO_INTERLEAVE", "RT_NO_LOOKAHEAD", "RT_NO_PAIR64", "RT_NO_PIPELINE", "RT_NO_PREP_OVERLAP", "RT_NO_SERIAL_TREES", "RT_NO_SMALL_TILES", "RT_NO_STATE_REUSE", "RT_NO_TRIM", "RT_PAD64_FROM", "RT_RNG_PRIO", "RT_STAGE_STREAMS", "RT_TILE_LOG2", "RT_UPLOAD_PAR_MIN"};
 constexpr int kNumOptions = (int)(sizeof(kOptionNames) / sizeof(kOptionNames[0]));
 struct OptionTable {
     std::mutex mu;
@@ -643,17 +643,76 @@ int copy_scene_to(rt_ctx::BackScene& bk, const rt::Scene& s, hipStream_t st) {
     if ((rc = bk.leaf_ext.ensure(std::max<size_t>(s.leaf_ext.size(), 2)))) return rc;
     if ((rc = bk.tris.ensure(s.tris.size()))) return rc;
     if ((rc = bk.colors.ensure(s.colors.size()))) return rc;
-    HIP_TRY(hipMemcpyAsync(bk.nodes.p, s.dev_nodes.data(), s.dev_nodes.size() * sizeof(rt::DevNode), hipMemcpyHostToDevice,
-                           st));
     HIP_TRY(hipMemcpyAsync(bk.tlas.p, s.dev_tlas.data(), s.dev_tlas.size() * sizeof(rt::DevNode), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(bk.slot_root.p, s.slot_root.data(), s.slot_root.size() * sizeof(int32_t), hipMemcpyHostToDevice,
                            st));
     if (!s.leaf_ext.empty())
         HIP_TRY(hipMemcpyAsync(bk.leaf_ext.p, s.leaf_ext.data(), s.leaf_ext.size() * sizeof(uint32_t), hipMemcpyHostToDevice,
                                st));
-    HIP_TRY(hipMemcpyAsync(bk.tris.p, s.tris.data(), s.tris.size() * sizeof(double), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(bk.colors.p, s.colors.data(), s.colors.size() * sizeof(double), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    // The three big arrays.  A copy from pageable memory is staged through the runtime's own pinned buffers by the
+    // thread that calls it -- one thread moves ~20 GiB/s on the GPU box, four ~31 (profiles/tools/h2d_threads.py) -- so
+    // a large scene's bytes are cut into four spans, three of them copied by helper threads on streams of their own.
+    struct Span {
+        char* dst;
+        const char* src;
+        size_t bytes;
+    };
+    const Span big[3] = {{reinterpret_cast<char*>(bk.nodes.p), reinterpret_cast<const char*>(s.dev_nodes.data()),
+                          s.dev_nodes.size() * sizeof(rt::DevNode)},
+                         {reinterpret_cast<char*>(bk.tris.p), reinterpret_cast<const char*>(s.tris.data()),
+                          s.tris.size() * sizeof(double)},
+                         {reinterpret_cast<char*>(bk.colors.p), reinterpret_cast<const char*>(s.colors.data()),
+                          s.colors.size() * sizeof(double)}};
+    const size_t total = big[0].bytes + big[1].bytes + big[2].bytes;
+    const size_t par_min = opt("RT_UPLOAD_PAR_MIN") ? (size_t)std::atoll(opt("RT_UPLOAD_PAR_MIN")) : (size_t(64) << 20);
+    constexpr int kParts = 4;
+    if (total < par_min) {
+        for (const Span& b : big) HIP_TRY(hipMemcpyAsync(b.dst, b.src, b.bytes, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        return RT_OK;
+    }
+    std::vector<Span> part[kParts];
+    {
+        const size_t per = ((total + kParts - 1) / kParts + 4095) & ~size_t(4095);
+        int k = 0;
+        size_t room = per;
+        for (const Span& b : big) {
+            size_t off = 0;
+            while (off < b.bytes) {
+                const size_t n = std::min(b.bytes - off, room);
+                part[k].push_back({b.dst + off, b.src + off, n});
+                off += n;
+                room -= n;
+                if (room == 0 && k + 1 < kParts) {
+                    ++k;
+                    room = per;
+                }
+            }
+        }
+    }
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    hipError_t err[kParts];
+    auto run = [&](int k, hipStream_t q) {
+        err[k] = hipSuccess;
+        for (const Span& sp : part[k])
+            if (err[k] == hipSuccess) err[k] = hipMemcpyAsync(sp.dst, sp.src, sp.bytes, hipMemcpyHostToDevice, q);
+        const hipError_t e = hipStreamSynchronize(q);
+        if (err[k] == hipSuccess) err[k] = e;
+    };
+    std::thread helpers[kParts - 1];
+    for (int k = 1; k < kParts; ++k)
+        helpers[k - 1] = std::thread([&, k]() {
+            hipStream_t q = nullptr;
+            err[k] = hipSetDevice(dev);
+            if (err[k] == hipSuccess) err[k] = hipStreamCreateWithFlags(&q, hipStreamNonBlocking);
+            if (err[k] != hipSuccess) return;
+            run(k, q);
+            (void)hipStreamDestroy(q);
+        });
+    run(0, st);
+    for (auto& h : helpers) h.join();
+    for (int k = 0; k < kParts; ++k) HIP_TRY(err[k]);
     return RT_OK;
 }
 
