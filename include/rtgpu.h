@@ -68,6 +68,11 @@ void rt_host_free(void *p);
 /* pool, every tree built by one thread: least CPU time, for callers   */
 /* that keep several builds in flight on threads of their own, as      */
 /* rt_render_scene does); results do not depend on it.                 */
+/* Returns NULL (rt_last_error) on invalid arguments, and when a        */
+/* triangle's centroid -- or, with more than two meshes, the centre of  */
+/* a mesh's box -- is a NaN or an infinity in a mesh that is split at   */
+/* all (more than 4 triangles): the reference's bin index               */
+/* static_cast<int>(t * NUM_BINS), rtbvh.cpp:184, is undefined there.   */
 /* ------------------------------------------------------------------ */
 rt_scene *rt_scene_build(int n_meshes, const double *const *coords, const double *const *colors,
                          const int64_t *elem_counts, int timestep, int n_threads);
