@@ -692,3 +692,21 @@ def test_learnt_sampler_stream_count_keeps_the_stream(ctx, monkeypatch):
             time.sleep(0.5)  # the helper thread's polynomials are there by now
     assert streams[0] >= 1 and max(streams) > streams[0], streams  # the count did change on the way
     host.close()
+
+
+@pytest.mark.parametrize("par_min", ["0", "100000"])
+def test_scene_uploaded_as_four_spans_by_four_threads(ctx, monkeypatch, par_min):
+    """Scenes of RT_UPLOAD_PAR_MIN bytes and more (default 64 MiB) are uploaded as four spans, three of them by helper
+    threads on streams of their own; the spans are cut at 4 KiB multiples of the three big arrays laid end to end, so they
+    cross array borders and, for small scenes, some are empty.  Forced here for scenes of a few KB to a few hundred KB:
+    the frames must stay the oracle's."""
+    monkeypatch.setenv("RT_UPLOAD_PAR_MIN", par_min)
+    rng = np.random.default_rng(8)
+    for n_tris in (1, 7, 40, 333, 2500):
+        coords, colors = [], []
+        for m in range(int(rng.integers(1, 4))):
+            c, k = meshgen.random_soup(n_tris, seed=int(rng.integers(1 << 30)), extent=3.0, size=0.8, z_range=(-7.0, -5.0))
+            coords.append(c)
+            colors.append(k * (0.3 + 0.2 * m))
+        cam = meshgen.camera_arrays(40, 24)
+        check_image(ctx, coords, colors, cam, 24, 40, 3)
